@@ -1,0 +1,88 @@
+"""ctypes binding of libcvaegan_hip.so (declarations: include/cvaegan.h).
+
+The library is the only compute path of this package.  If it is missing the import
+fails loudly; there is no CPU or PyTorch fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcvaegan_hip.so")
+
+F32, BF16 = 0, 1
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "B", "H", "W", "Cin", "x_img_pitch", "x_row_pitch", "x_pix_pitch",
+        "OH", "OW", "N", "KW", "ntaps", "stride", "tstep_y", "tstep_x", "off_y", "off_x",
+        "pad_mode", "y_img_pitch", "y_row_pitch", "y_pix_pitch", "oy_mul", "oy_off",
+        "ox_mul", "ox_off", "w_ld", "w_rows")]
+
+
+class WMap(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nd", "na", "nb", "kd", "ka", "kb", "n_valid", "kc_valid", "ntaps", "tap_mode")] + \
+        [("tap_table", C.c_int16 * 64)]
+
+
+class CvgError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "cvae_gan_amd: %s is missing. Build it with `make` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`) at the repository root; "
+            "this package has no fallback compute path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "cvg_version": (C.c_int, []),
+        "cvg_last_error": (C.c_char_p, []),
+        "cvg_conv_fwd_workspace": (sz, [P(ConvDesc)]),
+        "cvg_conv_fwd": (C.c_int, [P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "cvg_conv_wgrad_workspace": (sz, [P(ConvDesc)]),
+        "cvg_conv_wgrad": (C.c_int, [P(ConvDesc), vp, vp, i32, P(WMap), vp, i32, vp, sz, vp]),
+        "cvg_weight_pack": (C.c_int, [P(WMap), vp, vp, i32, i32, i32, vp]),
+        "cvg_label_bias": (C.c_int, [vp, vp, i32, i32, vp]),
+        "cvg_label_bias_bwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "cvg_pack_image": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "cvg_bn_stats_blocks": (i32, [i32, i32]),
+        "cvg_bn_stats": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "cvg_bn_act_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+        "cvg_bn_eval_stats": (C.c_int, [vp, vp, i32, vp, vp]),
+        "cvg_bn_act_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "cvg_colsum": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
+        "cvg_permute_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+        "cvg_reparam_kl_fwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
+        "cvg_reparam_kl_bwd": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
+        "cvg_lrelu_dropout_fwd": (C.c_int, [vp, vp, vp, i32, i64, vp]),
+        "cvg_lrelu_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i32, i64, vp]),
+        "cvg_dropout_mask": (C.c_int, [vp, i64, C.c_uint64, vp]),
+        "cvg_upsample_pad_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+        "cvg_upsample_pad_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+        "cvg_reflect_fold": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+        "cvg_tanh_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "cvg_tanh_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+        "cvg_mse_fwd_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, vp, vp]),
+        "cvg_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+        "cvg_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
+        "cvg_nhwc_to_nchw": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
+        "cvg_nchw_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise CvgError(lib.cvg_last_error().decode())

@@ -1,0 +1,829 @@
+// HBM-bound kernels of the CVAE train step for gfx950: BatchNorm (+LeakyReLU,
+// +residual) forward/backward, column reductions, reparameterisation + KL,
+// dropout, bilinear-upsample + reflection pad and their transposes, tanh + MSE,
+// AdamW, layout helpers.  All of them move 16 bytes per lane per access on NHWC
+// rows and reduce with per-thread accumulators -> LDS -> per-block partials ->
+// a small finalize kernel (fixed summation order: results are run-to-run stable).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLOPE * v; }
+
+// ---- column reductions over rows[M][ld] ----------------------------------------------
+// Thread layout: chunk = tid % CC handles 8 channels, rl = tid / CC strides the rows.
+enum { RED_STATS = 0, RED_BNBWD = 1, RED_SUM = 2 };
+
+struct RedArgs {
+    const void* x;       // STATS/SUM: input rows; BNBWD: conv output x
+    const void* dy;      // BNBWD
+    const void* y;       // BNBWD: activation output (sign source)
+    const float* stats;  // BNBWD: mean[C], invstd[C]
+    float* ws;           // partials [2][nblk][C]
+    int M, C, ld, nblk;
+    int Cb;              // columns handled per blockIdx.y (== C unless C > 1024)
+};
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
+    const int CC = a.Cb / 8;
+    const int RL = blockDim.x / CC;
+    const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
+    const int c_off = blockIdx.y * a.Cb;
+    __shared__ float sm[2][256][8];
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    float mean[8], istd[8];
+    if (MODE == RED_BNBWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mean[j] = a.stats[c_off + chunk * 8 + j]; istd[j] = a.stats[a.C + c_off + chunk * 8 + j]; }
+    }
+    if (rl < RL) {
+        for (int64_t m = (int64_t)blockIdx.x * RL + rl; m < a.M; m += (int64_t)gridDim.x * RL) {
+            const size_t off = (size_t)m * a.ld + c_off + chunk * 8;
+            float v[8];
+            load8<T>((const T*)a.x + off, v);
+            if (MODE == RED_STATS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * v[j]; }
+            } else if (MODE == RED_SUM) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s0[j] += v[j];
+            } else {
+                float d[8], o[8];
+                load8<T>((const T*)a.dy + off, d);
+                load8<T>((const T*)a.y + off, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
+                    s0[j] += g;
+                    s1[j] += g * (v[j] - mean[j]) * istd[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sm[0][threadIdx.x][j] = s0[j]; sm[1][threadIdx.x][j] = s1[j]; }
+    __syncthreads();
+    // thread t < 2*C sums column (t % C) of partial (t / C) over the row lanes
+    for (int t = threadIdx.x; t < 2 * a.Cb; t += blockDim.x) {
+        const int which = t / a.Cb, col = t % a.Cb;
+        const int ch = col / 8, j = col % 8;
+        float s = 0.f;
+        for (int r = 0; r < RL; ++r) s += sm[which][r * CC + ch][j];
+        a.ws[((size_t)which * a.nblk + blockIdx.x) * a.C + c_off + col] = s;
+    }
+}
+
+__global__ void stats_finalize(const float* __restrict__ ws, int nblk, int M, int C, float* __restrict__ stats,
+                               float* running_mean, float* running_var, long long* nbt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += ws[(size_t)b * C + c]; ss += ws[((size_t)nblk + b) * C + c]; }
+    const double mean = s / M;
+    double var = ss / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    if (running_mean) {
+        const double unb = M > 1 ? var * ((double)M / (M - 1)) : var;
+        running_mean[c] = (1.f - BN_MOMENTUM) * running_mean[c] + BN_MOMENTUM * (float)mean;
+        running_var[c] = (1.f - BN_MOMENTUM) * running_var[c] + BN_MOMENTUM * (float)unb;
+    }
+}
+
+__global__ void eval_stats(const float* rm, const float* rv, int C, float* stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    stats[c] = rm[c];
+    stats[C + c] = 1.f / sqrtf(rv[c] + BN_EPS);
+}
+
+// sums partials; out0[map(c)] = sum of partial 0, out1[c] = sum of partial 1 (optional)
+__global__ void sum_finalize(const float* __restrict__ ws, int nblk, int C, float* out0, float* out1, int md, int ma,
+                             int mb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, t = 0.f;
+    for (int b = 0; b < nblk; ++b) { s += ws[(size_t)b * C + c]; if (out1) t += ws[((size_t)nblk + b) * C + c]; }
+    out0[(c / md) * ma + (c % md) * mb] = s;
+    if (out1) out1[c] = t;
+}
+
+// ---- BatchNorm + LeakyReLU apply -------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_fwd(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                  int M, int C, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta) {
+    const int CC = C / 8, RL = blockDim.x / CC;
+    const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
+    if (rl >= RL) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        sc[j] = gamma[c] * stats[C + c];
+        sh[j] = beta[c] - stats[c] * sc[j];
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RL + rl; m < M; m += (int64_t)gridDim.x * RL) {
+        const size_t off = (size_t)m * C + chunk * 8;
+        float v[8];
+        load8<T>(x + off, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+        if (res) {
+            float r[8];
+            load8<T>(res + off, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = lrelu(v[j]);
+        store8<T>(y + off, v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, const T* __restrict__ y,
+                                                     const T* __restrict__ x, T* __restrict__ dx, int M, int C,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const int CC = C / 8, RL = blockDim.x / CC;
+    const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
+    if (rl >= RL) return;
+    float mean[8], istd[8], k0[8], k1[8], k2[8];
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        mean[j] = stats[c];
+        istd[j] = stats[C + c];
+        k0[j] = gamma[c] * istd[j];
+        k1[j] = dbeta[c] * invM;
+        k2[j] = dgamma[c] * invM;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RL + rl; m < M; m += (int64_t)gridDim.x * RL) {
+        const size_t off = (size_t)m * C + chunk * 8;
+        float d[8], o[8], v[8];
+        load8<T>(dy + off, d);
+        load8<T>(y + off, o);
+        load8<T>(x + off, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
+            const float xh = (v[j] - mean[j]) * istd[j];
+            v[j] = k0[j] * (g - k1[j] - xh * k2[j]);
+        }
+        store8<T>(dx + off, v);
+    }
+}
+
+// ---- small vector helpers -----------------------------------------------------------------
+__global__ void permute_f32(const float* in, float* out, int n, int d, int a, int b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[(i / d) * a + (i % d) * b];
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* in, TO* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = from_f32<TO>(to_f32(in[i]));
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw(const T* in, float* out, int B, int HW, int C, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*HW, hw fastest
+    if (i >= (int64_t)B * C * HW) return;
+    const int hw = (int)(i % HW), c = (int)((i / HW) % C), b = (int)(i / ((int64_t)HW * C));
+    out[i] = to_f32(in[((size_t)b * HW + hw) * ld + c]);
+}
+template <typename T>
+__global__ void nchw_to_nhwc(const float* in, T* out, int B, int HW, int C, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*ld, channel fastest
+    if (i >= (int64_t)B * HW * ld) return;
+    const int c = (int)(i % ld), hw = (int)((i / ld) % HW), b = (int)(i / ((int64_t)ld * HW));
+    out[i] = from_f32<T>(c < C ? in[((size_t)b * C + c) * HW + hw] : 0.f);
+}
+
+// ---- stem input: NCHW f32 -> reflection-padded NHWC4 -----------------------------------------
+template <typename T>
+__global__ void pack_image(const float* __restrict__ x, T* __restrict__ xp, int B, int P) {
+    const int Wp = P + 8, Hp = P + 6;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * Hp * Wp) return;
+    const int px = (int)(i % Wp), py = (int)((i / Wp) % Hp), b = (int)(i / ((int64_t)Wp * Hp));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (px < P + 6) {
+        int sy = py - 3, sx = px - 3;
+        sy = sy < 0 ? -sy : (sy >= P ? 2 * P - 2 - sy : sy);
+        sx = sx < 0 ? -sx : (sx >= P ? 2 * P - 2 - sx : sx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = x[(((size_t)b * 3 + c) * P + sy) * P + sx];
+    }
+    store4<T>(xp + (size_t)i * 4, v);
+}
+
+// ---- label fold ------------------------------------------------------------------------------
+__global__ void label_bias(const float* __restrict__ w, float* __restrict__ cbias, int cout, int y_dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over y_dim*cout, n fastest
+    if (i >= y_dim * cout) return;
+    const int n = i % cout, c = i / cout;
+    const float* p = w + ((size_t)n * (3 + y_dim) + 3 + c) * 49;
+    float s = 0.f;
+    for (int t = 0; t < 49; ++t) s += p[t];
+    cbias[i] = s;
+}
+// S[b][n] = sum over the image's pixels of dy[b][pix][n]; one block per image
+template <typename T>
+__global__ void __launch_bounds__(256) per_image_colsum(const T* __restrict__ dy, float* __restrict__ S, int pixels,
+                                                        int C) {
+    const int CC = C / 8, RL = blockDim.x / CC;
+    const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
+    __shared__ float sm[256][8];
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    const T* base = dy + (size_t)blockIdx.x * pixels * C;
+    if (rl < RL)
+        for (int m = rl; m < pixels; m += RL) {
+            float v[8];
+            load8<T>(base + (size_t)m * C + chunk * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm[threadIdx.x][j] = s[j];
+    __syncthreads();
+    for (int col = threadIdx.x; col < C; col += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < RL; ++r) t += sm[r * CC + col / 8][col % 8];
+        S[(size_t)blockIdx.x * C + col] = t;
+    }
+}
+__global__ void label_bias_scatter(const float* __restrict__ S, const int* __restrict__ labels, int B, int cout,
+                                   int y_dim, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over (y_dim + 1) * cout
+    if (i >= (y_dim + 1) * cout) return;
+    const int n = i % cout, c = i / cout;
+    float s = 0.f;
+    if (c == y_dim) {
+        for (int b = 0; b < B; ++b) s += S[(size_t)b * cout + n];
+        if (dbias) dbias[n] = s;
+        return;
+    }
+    for (int b = 0; b < B; ++b) if (labels[b] == c) s += S[(size_t)b * cout + n];
+    float* p = dw + ((size_t)n * (3 + y_dim) + 3 + c) * 49;
+    for (int t = 0; t < 49; ++t) p[t] = s;
+}
+
+// ---- reparameterisation + KL -----------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) reparam_kl_fwd(const T* __restrict__ h, const float* __restrict__ eps,
+                                                       const int* __restrict__ labels, int B, int z, int y_dim,
+                                                       int zin_ld, T* __restrict__ zin, float* __restrict__ z_mean,
+                                                       float* __restrict__ z_sigma, float* __restrict__ kl,
+                                                       float batch_size) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B * zin_ld; i += blockDim.x) {
+        const int b = i / zin_ld, j = i % zin_ld;
+        float out = 0.f;
+        if (j < z) {
+            const float mu = to_f32(h[(size_t)b * 2 * z + j]);
+            const float ls = to_f32(h[(size_t)b * 2 * z + z + j]);
+            const float sg = expf(ls);
+            out = mu + sg * eps[b * z + j];
+            z_mean[b * z + j] = mu;
+            z_sigma[b * z + j] = sg;
+            acc += mu * mu + sg * sg - 2.f * ls - 1.f;     // log(sigma^2) = 2 * log_sigma
+        } else if (j < z + y_dim) {
+            out = labels[b] == j - z ? 1.f : 0.f;
+        }
+        zin[i] = from_f32<T>(out);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        *kl = s / ((float)B * (float)z) / batch_size;
+    }
+}
+
+template <typename T>
+__global__ void reparam_kl_bwd(const T* __restrict__ dzin, int zin_ld, const float* __restrict__ eps,
+                               const float* __restrict__ z_mean, const float* __restrict__ z_sigma,
+                               const float* __restrict__ g_mean, const float* __restrict__ g_sigma, float kl_scale,
+                               float batch_size, int B, int z, T* __restrict__ dh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * z) return;
+    const int b = i / z, j = i % z;
+    const float dz = to_f32(dzin[(size_t)b * zin_ld + j]);
+    const float mu = z_mean[i], sg = z_sigma[i];
+    const float s = kl_scale / ((float)B * (float)z * batch_size);
+    float dmu = dz + 2.f * mu * s;
+    float dsg = dz * eps[i];
+    if (g_mean) dmu += g_mean[i];
+    if (g_sigma) dsg += g_sigma[i];
+    const float dls = dsg * sg + (2.f * sg * sg - 2.f) * s;
+    dh[(size_t)b * 2 * z + j] = from_f32<T>(dmu);
+    dh[(size_t)b * 2 * z + z + j] = from_f32<T>(dls);
+}
+
+// ---- LeakyReLU + Dropout(0.5) ------------------------------------------------------------------
+template <typename T>
+__global__ void lrelu_dropout_fwd(const T* __restrict__ x, const uint8_t* __restrict__ mask, T* __restrict__ y,
+                                  int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    float v[8];
+    load8<T>(x + i, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = lrelu(v[j]);
+        if (mask) v[j] = mask[i + j] ? 2.f * v[j] : 0.f;
+    }
+    store8<T>(y + i, v);
+}
+template <typename T>
+__global__ void lrelu_dropout_bwd(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask,
+                                  T* __restrict__ dx, int64_t n) {
+    // y = lrelu(x) * (mask ? 2 : 0): sign(y) = sign(x) wherever the mask keeps the value
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    float d[8], o[8];
+    load8<T>(dy + i, d);
+    load8<T>(y + i, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
+        if (mask) g = mask[i + j] ? 2.f * g : 0.f;
+        d[j] = g;
+    }
+    store8<T>(dx + i, d);
+}
+__global__ void dropout_mask(uint8_t* mask, int64_t n, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t v = (uint64_t)i + seed * 0x9E3779B97F4A7C15ull;      // splitmix64 finaliser
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    v ^= v >> 31;
+    mask[i] = (uint8_t)((v >> 40) & 1u);
+}
+
+// ---- bilinear x2 + reflection pad 1 --------------------------------------------------------------
+// Up-sampled coordinate p in [0, 2h): source rows and weights exactly as
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False).
+__device__ __forceinline__ void up_src(int p, int h, int& i0, int& i1, float& w0, float& w1) {
+    if (p == 0) { i0 = 0; i1 = h > 1 ? 1 : 0; w0 = 1.f; w1 = 0.f; return; }
+    const int i = p >> 1;
+    if (p & 1) { i0 = i; i1 = i + 1 < h ? i + 1 : h - 1; w0 = 0.75f; w1 = 0.25f; }
+    else { i0 = i - 1; i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}
+__device__ __forceinline__ int unpad_reflect1(int u, int n2) {      // padded index u in [0, n2+2) -> [0, n2)
+    const int p = u - 1;
+    return p < 0 ? 1 : (p >= n2 ? n2 - 2 : p);
+}
+
+template <typename T>
+__global__ void upsample_pad_fwd(const T* __restrict__ x, T* __restrict__ u, int B, int h, int w, int C) {
+    const int CC = C / 8, UH = 2 * h + 2, UW = 2 * w + 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * UH * UW * CC) return;
+    const int ch = (int)(i % CC);
+    const int ux = (int)((i / CC) % UW), uy = (int)((i / ((int64_t)CC * UW)) % UH);
+    const int b = (int)(i / ((int64_t)CC * UW * UH));
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    up_src(unpad_reflect1(uy, 2 * h), h, y0, y1, wy0, wy1);
+    up_src(unpad_reflect1(ux, 2 * w), w, x0, x1, wx0, wx1);
+    const T* base = x + (size_t)b * h * w * C + ch * 8;
+    float a[8], bb[8], c[8], d[8], o[8];
+    load8<T>(base + ((size_t)y0 * w + x0) * C, a);
+    load8<T>(base + ((size_t)y0 * w + x1) * C, bb);
+    load8<T>(base + ((size_t)y1 * w + x0) * C, c);
+    load8<T>(base + ((size_t)y1 * w + x1) * C, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * bb[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
+    store8<T>(u + (size_t)i * 8, o);
+}
+
+// Per-axis gather list of the transpose: which padded positions feed input index i, and with what weight.
+__device__ __forceinline__ int up_bwd_list(int i, int h, int (&pos)[8], float (&wt)[8]) {
+    int n = 0;
+    const int n2 = 2 * h;
+    for (int p = 2 * i - 1; p <= 2 * i + 2; ++p) {
+        if (p < 0 || p >= n2) continue;
+        int i0, i1;
+        float w0, w1;
+        up_src(p, h, i0, i1, w0, w1);
+        const float wgt = (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
+        if (wgt == 0.f) continue;
+        pos[n] = p + 1; wt[n] = wgt; ++n;
+        if (p == 1) { pos[n] = 0; wt[n] = wgt; ++n; }                  // padded row 0 mirrors p = 1
+        if (p == n2 - 2) { pos[n] = n2 + 1; wt[n] = wgt; ++n; }        // padded row n2+1 mirrors p = n2-2
+    }
+    return n;
+}
+
+template <typename T>
+__global__ void upsample_pad_bwd(const T* __restrict__ du, T* __restrict__ dx, int B, int h, int w, int C) {
+    const int CC = C / 8, UH = 2 * h + 2, UW = 2 * w + 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * h * w * CC) return;
+    const int ch = (int)(i % CC);
+    const int ix = (int)((i / CC) % w), iy = (int)((i / ((int64_t)CC * w)) % h);
+    const int b = (int)(i / ((int64_t)CC * w * h));
+    int py[8], px[8];
+    float wy[8], wx[8];
+    const int ny = up_bwd_list(iy, h, py, wy), nx = up_bwd_list(ix, w, px, wx);
+    const T* base = du + (size_t)b * UH * UW * C + ch * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int a = 0; a < ny; ++a)
+        for (int c = 0; c < nx; ++c) {
+            float v[8];
+            load8<T>(base + ((size_t)py[a] * UW + px[c]) * C, v);
+            const float wgt = wy[a] * wx[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * v[j];
+        }
+    store8<T>(dx + (size_t)i * 8, acc);
+}
+
+// transpose of ReflectionPad2d(pad)
+__device__ __forceinline__ int fold_list(int y, int H, int pad, int (&pos)[3]) {
+    int n = 0;
+    pos[n++] = y + pad;
+    if (y >= 1 && y <= pad) pos[n++] = pad - y;
+    if (y <= H - 2 && y >= H - 1 - pad) pos[n++] = pad + 2 * H - 2 - y;
+    return n;
+}
+template <typename T>
+__global__ void reflect_fold(const T* __restrict__ dxp, T* __restrict__ dx, int B, int H, int W, int C, int pad) {
+    const int CC = C / 8, Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H * W * CC) return;
+    const int ch = (int)(i % CC);
+    const int x = (int)((i / CC) % W), y = (int)((i / ((int64_t)CC * W)) % H);
+    const int b = (int)(i / ((int64_t)CC * W * H));
+    int py[3], px[3];
+    const int ny = fold_list(y, H, pad, py), nx = fold_list(x, W, pad, px);
+    const T* base = dxp + (size_t)b * Hp * Wp * C + ch * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int a = 0; a < ny; ++a)
+        for (int c = 0; c < nx; ++c) {
+            float v[8];
+            load8<T>(base + ((size_t)py[a] * Wp + px[c]) * C, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+    store8<T>(dx + (size_t)i * 8, acc);
+}
+
+// ---- tanh + MSE -------------------------------------------------------------------------------------
+template <typename T>
+__global__ void tanh_fwd(const T* __restrict__ pre, float* __restrict__ dec, int B, int PP) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*PP pixels
+    if (i >= (int64_t)B * PP) return;
+    const int b = (int)(i / PP), hw = (int)(i % PP);
+    float v[4];
+    load4<T>(pre + (size_t)i * 4, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dec[((size_t)b * 3 + c) * PP + hw] = tanhf(v[c]);
+}
+template <typename T>
+__global__ void tanh_bwd(const float* __restrict__ d_dec, const float* __restrict__ dec, T* __restrict__ dpre, int B,
+                         int PP) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * PP) return;
+    const int b = (int)(i / PP), hw = (int)(i % PP);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t o = ((size_t)b * 3 + c) * PP + hw;
+        const float t = dec[o];
+        v[c] = d_dec[o] * (1.f - t * t);
+    }
+    store8<T>(dpre + (size_t)i * 8, v);
+}
+
+__global__ void __launch_bounds__(256) mse_partial(const float* __restrict__ dec, const float* __restrict__ x,
+                                                   float* __restrict__ d_dec, float* __restrict__ ws, int64_t n,
+                                                   float coef) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = dec[i] - x[i];
+        acc += d * d;
+        d_dec[i] = coef * d;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse_finalize(const float* ws, int nblk, float* ll, float scale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += ws[b];
+        *ll = (float)(s * scale);
+    }
+}
+
+// ---- AdamW ------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float inv_bc1, float inv_sqrt_bc2) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 pp = *(f32x4*)(p + i), gg = *(const f32x4*)(g + i), mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pp[j] *= 1.f - lr * wd;
+            mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
+            vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
+            const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+            pp[j] -= lr * inv_bc1 * (mm[j] / denom);
+        }
+        *(f32x4*)(p + i) = pp; *(f32x4*)(m + i) = mm; *(f32x4*)(v + i) = vv;
+    } else {
+        for (int64_t k = i; k < n; ++k) {
+            float pp = p[k] * (1.f - lr * wd);
+            const float gg = g[k];
+            const float mm = b1 * m[k] + (1.f - b1) * gg;
+            const float vv = b2 * v[k] + (1.f - b2) * gg * gg;
+            pp -= lr * inv_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+            p[k] = pp; m[k] = mm; v[k] = vv;
+        }
+    }
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------------
+int red_threads(int C) { const int CC = C / 8; return CC * (256 / CC); }
+int red_blocks(int M, int C) {
+    const int RL = 256 / (C / 8);
+    int nb = ceil_div(M, (int64_t)RL * 8);
+    return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+}
+int check_rows(const char* who, int M, int C) {
+    CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && C <= 1024, "%s: M %d C %d (C must be a multiple of 8, <= 1024)", who, M, C);
+    return 0;
+}
+int col_block(int C) { return C <= 1024 ? C : 512; }
+int grid1(int64_t n, int per = 256) { return ceil_div(n, per); }
+
+}  // namespace
+
+#define DISPATCH(dtype, ...) do { if ((dtype) == CVG_BF16) { typedef bf16 T; __VA_ARGS__; } \
+    else if ((dtype) == CVG_F32) { typedef float T; __VA_ARGS__; } else CVG_FAIL("bad dtype %d", (int)(dtype)); } while (0)
+
+extern "C" {
+
+int cvg_pack_image(const float* x, void* xpad, int32_t B, int32_t P, int32_t dtype, cvg_stream stream) {
+    CVG_CHECK(x && xpad && B > 0 && P >= 8, "pack_image: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * (P + 6) * (P + 8);
+    DISPATCH(dtype, pack_image<T><<<grid1(n), 256, 0, s>>>(x, (T*)xpad, B, P));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int32_t cvg_bn_stats_blocks(int32_t M, int32_t C) { return red_blocks(M, C); }
+
+int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats, float* running_mean,
+                 float* running_var, int64_t* nbt, float* ws, cvg_stream stream) {
+    if (check_rows("bn_stats", M, C)) return -1;
+    CVG_CHECK(x && stats && ws, "bn_stats: null");
+    hipStream_t s = (hipStream_t)stream;
+    RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
+    DISPATCH(dtype, colreduce<T, RED_STATS><<<a.nblk, red_threads(C), 0, s>>>(a));
+    CVG_LAUNCH_CHECK();
+    stats_finalize<<<grid1(C, 128), 128, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_bn_eval_stats(const float* rm, const float* rv, int32_t C, float* stats, cvg_stream stream) {
+    CVG_CHECK(rm && rv && stats && C > 0, "bn_eval_stats: bad args");
+    eval_stats<<<grid1(C, 128), 128, 0, (hipStream_t)stream>>>(rm, rv, C, stats);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32_t M, int32_t C, const float* stats,
+                   const float* gamma, const float* beta, cvg_stream stream) {
+    if (check_rows("bn_act_fwd", M, C)) return -1;
+    CVG_CHECK(x && y && stats && gamma && beta, "bn_act_fwd: null");
+    const int RL = 256 / (C / 8);
+    int nb = ceil_div(M, (int64_t)RL * 4);
+    if (nb > 4096) nb = 4096;
+    DISPATCH(dtype, bn_act_fwd<T><<<nb, red_threads(C), 0, (hipStream_t)stream>>>((const T*)x, (const T*)res, (T*)y, M, C,
+                                                                                 stats, gamma, beta));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32_t dtype, int32_t M, int32_t C,
+                   const float* stats, const float* gamma, float* dgamma, float* dbeta, float* ws,
+                   cvg_stream stream) {
+    if (check_rows("bn_act_bwd", M, C)) return -1;
+    CVG_CHECK(dy && y && x && dx && stats && gamma && dgamma && dbeta && ws, "bn_act_bwd: null");
+    hipStream_t s = (hipStream_t)stream;
+    RedArgs a = {x, dy, y, stats, ws, M, C, C, red_blocks(M, C), C};
+    DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
+    CVG_LAUNCH_CHECK();
+    sum_finalize<<<grid1(C, 128), 128, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
+    CVG_LAUNCH_CHECK();
+    const int RL = 256 / (C / 8);
+    int nb = ceil_div(M, (int64_t)RL * 4);
+    if (nb > 4096) nb = 4096;
+    DISPATCH(dtype, bn_act_bwd_dx<T><<<nb, red_threads(C), 0, s>>>((const T*)dy, (const T*)y, (const T*)x, (T*)dx, M, C,
+                                                                   stats, gamma, dgamma, dbeta));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, float* out, int32_t md, int32_t ma,
+               int32_t mb, float* ws, cvg_stream stream) {
+    CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && (C <= 1024 || C % 512 == 0), "colsum: C %d must be <= 1024 or a multiple of 512", C);
+    CVG_CHECK(x && out && ws && ld >= C && ld % 8 == 0 && md > 0, "colsum: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cb = col_block(C);
+    RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
+    DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, C / Cb), red_threads(Cb), 0, s>>>(a));
+    CVG_LAUNCH_CHECK();
+    sum_finalize<<<grid1(C, 128), 128, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_permute_f32(const float* in, float* out, int32_t n, int32_t d, int32_t a, int32_t b, cvg_stream stream) {
+    CVG_CHECK(in && out && n > 0 && d > 0, "permute: bad args");
+    permute_f32<<<grid1(n), 256, 0, (hipStream_t)stream>>>(in, out, n, d, a, b);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_label_bias(const float* w, float* cbias, int32_t cout, int32_t y_dim, cvg_stream stream) {
+    CVG_CHECK(w && cbias && cout > 0 && y_dim > 0, "label_bias: bad args");
+    label_bias<<<grid1((int64_t)cout * y_dim), 256, 0, (hipStream_t)stream>>>(w, cbias, cout, y_dim);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_label_bias_bwd(const void* dy, int32_t dtype, const int32_t* labels, int32_t B, int32_t pixels, int32_t cout,
+                       int32_t y_dim, float* dw, float* dbias, float* ws, cvg_stream stream) {
+    if (check_rows("label_bias_bwd", pixels, cout)) return -1;
+    CVG_CHECK(dy && labels && dw && ws && B > 0, "label_bias_bwd: null");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype, per_image_colsum<T><<<B, red_threads(cout), 0, s>>>((const T*)dy, ws, pixels, cout));
+    CVG_LAUNCH_CHECK();
+    label_bias_scatter<<<grid1((int64_t)(y_dim + 1) * cout), 256, 0, s>>>(ws, labels, B, cout, y_dim, dw, dbias);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_reparam_kl_fwd(const void* h, int32_t dtype, const float* eps, const int32_t* labels, int32_t B, int32_t z,
+                       int32_t y_dim, int32_t zin_ld, void* zin, float* z_mean, float* z_sigma, float* kl,
+                       float batch_size, cvg_stream stream) {
+    CVG_CHECK(h && eps && labels && zin && z_mean && z_sigma && kl, "reparam_kl_fwd: null");
+    CVG_CHECK(zin_ld >= z + y_dim && zin_ld % 8 == 0 && B > 0 && z > 0, "reparam_kl_fwd: bad dims");
+    DISPATCH(dtype, reparam_kl_fwd<T><<<1, 1024, 0, (hipStream_t)stream>>>((const T*)h, eps, labels, B, z, y_dim, zin_ld,
+                                                                          (T*)zin, z_mean, z_sigma, kl, batch_size));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_reparam_kl_bwd(const void* dzin, int32_t dtype, int32_t zin_ld, const float* eps, const float* z_mean,
+                       const float* z_sigma, const float* g_mean, const float* g_sigma, float kl_scale,
+                       float batch_size, int32_t B, int32_t z, void* dh, cvg_stream stream) {
+    CVG_CHECK(dzin && eps && z_mean && z_sigma && dh && B > 0 && z > 0, "reparam_kl_bwd: bad args");
+    DISPATCH(dtype, reparam_kl_bwd<T><<<grid1((int64_t)B * z), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_lrelu_dropout_fwd(const void* x, const uint8_t* mask, void* y, int32_t dtype, int64_t n, cvg_stream stream) {
+    CVG_CHECK(x && y && n > 0 && n % 8 == 0, "lrelu_dropout_fwd: n must be a positive multiple of 8");
+    DISPATCH(dtype, lrelu_dropout_fwd<T><<<grid1(n / 8), 256, 0, (hipStream_t)stream>>>((const T*)x, mask, (T*)y, n));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_lrelu_dropout_bwd(const void* dy, const void* y, const uint8_t* mask, void* dx, int32_t dtype, int64_t n,
+                          cvg_stream stream) {
+    CVG_CHECK(dy && y && dx && n > 0 && n % 8 == 0, "lrelu_dropout_bwd: n must be a positive multiple of 8");
+    DISPATCH(dtype, lrelu_dropout_bwd<T><<<grid1(n / 8), 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)y, mask,
+                                                                                      (T*)dx, n));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, cvg_stream stream) {
+    CVG_CHECK(mask && n > 0, "dropout_mask: bad args");
+    dropout_mask<<<grid1(n), 256, 0, (hipStream_t)stream>>>(mask, n, seed);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_upsample_pad_fwd(const void* x, void* u, int32_t dtype, int32_t B, int32_t h, int32_t w, int32_t C,
+                         cvg_stream stream) {
+    CVG_CHECK(x && u && B > 0 && h > 0 && w > 0 && C % 8 == 0, "upsample_pad_fwd: bad args");
+    const int64_t n = (int64_t)B * (2 * h + 2) * (2 * w + 2) * (C / 8);
+    DISPATCH(dtype, upsample_pad_fwd<T><<<grid1(n), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)u, B, h, w, C));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int32_t h, int32_t w, int32_t C,
+                         cvg_stream stream) {
+    CVG_CHECK(du && dx && B > 0 && h > 0 && w > 0 && C % 8 == 0, "upsample_pad_bwd: bad args");
+    const int64_t n = (int64_t)B * h * w * (C / 8);
+    DISPATCH(dtype, upsample_pad_bwd<T><<<grid1(n), 256, 0, (hipStream_t)stream>>>((const T*)du, (T*)dx, B, h, w, C));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad,
+                     cvg_stream stream) {
+    CVG_CHECK(dxp && dx && B > 0 && pad >= 0 && pad < H && pad < W && C % 8 == 0, "reflect_fold: bad args");
+    const int64_t n = (int64_t)B * H * W * (C / 8);
+    DISPATCH(dtype, reflect_fold<T><<<grid1(n), 256, 0, (hipStream_t)stream>>>((const T*)dxp, (T*)dx, B, H, W, C, pad));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_tanh_fwd(const void* pre, float* dec, int32_t dtype, int32_t B, int32_t P, cvg_stream stream) {
+    CVG_CHECK(pre && dec && B > 0 && P > 0, "tanh_fwd: bad args");
+    DISPATCH(dtype, tanh_fwd<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>((const T*)pre, dec, B, P * P));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, int32_t dtype, int32_t B, int32_t P,
+                 cvg_stream stream) {
+    CVG_CHECK(d_dec && dec && dpre && B > 0 && P > 0, "tanh_bwd: bad args");
+    DISPATCH(dtype, tanh_bwd<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>(d_dec, dec, (T*)dpre, B, P * P));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, int64_t numel, float batch_size,
+                    float scale, float* ws, cvg_stream stream) {
+    CVG_CHECK(dec && x && d_dec && ll && ws && numel > 0 && batch_size > 0, "mse: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = grid1(numel, 256 * 8);
+    if (nb > 1024) nb = 1024;
+    const float coef = scale * 100.f / ((float)numel * batch_size);
+    mse_partial<<<nb, 256, 0, s>>>(dec, x, d_dec, ws, numel, coef);
+    CVG_LAUNCH_CHECK();
+    mse_finalize<<<1, 64, 0, s>>>(ws, nb, ll, 50.f / ((float)numel * batch_size));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int32_t step, cvg_stream stream) {
+    CVG_CHECK(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    adamw_kernel<<<grid1(ceil_div(n, 4)), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                                                                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n, cvg_stream stream) {
+    CVG_CHECK(in && out && n > 0, "cast: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid1(n);
+    if (in_dtype == CVG_F32 && out_dtype == CVG_BF16) cast_kernel<float, bf16><<<g, 256, 0, s>>>((const float*)in, (bf16*)out, n);
+    else if (in_dtype == CVG_BF16 && out_dtype == CVG_F32) cast_kernel<bf16, float><<<g, 256, 0, s>>>((const bf16*)in, (float*)out, n);
+    else if (in_dtype == CVG_F32 && out_dtype == CVG_F32) cast_kernel<float, float><<<g, 256, 0, s>>>((const float*)in, (float*)out, n);
+    else if (in_dtype == CVG_BF16 && out_dtype == CVG_BF16) cast_kernel<bf16, bf16><<<g, 256, 0, s>>>((const bf16*)in, (bf16*)out, n);
+    else CVG_FAIL("cast: bad dtypes");
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_nhwc_to_nchw(const void* in, int32_t dtype, float* out, int32_t B, int32_t HW, int32_t C, int32_t ld,
+                     cvg_stream stream) {
+    CVG_CHECK(in && out && ld >= C, "nhwc_to_nchw: bad args");
+    DISPATCH(dtype, nhwc_to_nchw<T><<<grid1((int64_t)B * C * HW), 256, 0, (hipStream_t)stream>>>((const T*)in, out, B, HW, C, ld));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_nchw_to_nhwc(const float* in, void* out, int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t ld,
+                     cvg_stream stream) {
+    CVG_CHECK(in && out && ld >= C, "nchw_to_nhwc: bad args");
+    DISPATCH(dtype, nchw_to_nhwc<T><<<grid1((int64_t)B * HW * ld), 256, 0, (hipStream_t)stream>>>(in, (T*)out, B, HW, C, ld));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,630 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X).
+//
+// One gather geometry (cvg_conv_desc) serves Conv2d forward, input gradient, Linear
+// layers and weight gradients.  Activations are NHWC, so the 8 consecutive k values
+// of an MFMA fragment are 8 consecutive channels of one tap: a single 16-byte read.
+//
+//   igemm_fwd    Y[m][n] = sum_k gather(X)[m][k] * W[n][k]         (reduce over k)
+//   igemm_wgrad  P[n][k] = sum_m dY[m][n] * gather(X)[m][k]         (reduce over m)
+//
+// Both are LDS-staged, register-prefetched two-stage pipelines with 4 waves per
+// workgroup and 64x64 (or 64x32 / 32x32) per-wave tiles of 32x32 MFMA blocks.
+// T = bf16 uses v_mfma_f32_32x32x16_bf16; T = float uses v_mfma_f32_32x32x2_f32,
+// which is an exact f32 fma chain and serves as the tight-tolerance parity mode.
+#include "common.h"
+
+namespace {
+
+struct Geom {
+    int H, W, Cin, cin_log2;
+    int x_img_pitch, x_row_pitch, x_pix_pitch;
+    int KW, kw_inv, ntaps, stride, tstep_y, tstep_x, off_y, off_x, pad_mode;
+    int Kvalid, M, OW, OHW;
+    FastDiv div_ohw, div_ow;
+};
+
+struct FwdArgs {
+    Geom g;
+    const void* x; const void* w; void* y;
+    const float* bias; const float* cbias; const int* labels;
+    const void* res; const void* gate; float* ws;
+    int N, w_ld;
+    int y_img_pitch, y_row_pitch, y_pix_pitch, oy_mul, oy_off, ox_mul, ox_off;
+    int nk_total, nk_per_split, ksplit;
+};
+
+struct WgradArgs {
+    Geom g;
+    const void* x; const void* dy; float* ws;
+    int dy_ld, n_rows, k_ld;          // partial layout [split][n_rows][k_ld]
+    int nsteps_total, steps_per_split;
+};
+
+// tap index -> gathered-coordinate offset
+__device__ __forceinline__ void tap_offset(const Geom& g, int tap, int& dy, int& dx) {
+    int ty = (tap * g.kw_inv) >> 16;
+    int tx = tap - ty * g.KW;
+    dy = ty * g.tstep_y + g.off_y;
+    dx = tx * g.tstep_x + g.off_x;
+}
+
+// Coordinates after padding; returns false when the element is a structural zero.
+__device__ __forceinline__ bool pad_coord(const Geom& g, int& iy, int& ix) {
+    if (g.pad_mode == CVG_PAD_REFLECT) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= g.H ? 2 * g.H - 2 - iy : iy;
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= g.W ? 2 * g.W - 2 - ix : ix;
+        return true;
+    }
+    return (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+}
+
+// ================================================================================
+// forward / input-gradient kernel
+// ================================================================================
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_fwd(const FwdArgs a) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int BK = 8 * VEC;                 // 128 bytes of k per row and step
+    constexpr int PITCH = 144;                  // LDS row pitch: 128 B + 16 B pad (conflict-free b128 reads)
+    constexpr int AR = BM / 32, BR = BN / 32;   // rows per thread per tile
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+    constexpr int STAGE = (BM + BN) * PITCH;
+    typedef typename Elem<T>::frag frag;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T* __restrict__ xp = (const T*)a.x;
+    const T* __restrict__ wp = (const T*)a.w;
+
+    // ---- loader bookkeeping: this thread fetches 16-byte chunk `cc` of rows r0+32i
+    const int cc = tid & 7, r0 = tid >> 3;
+    int riy[AR], rix[AR], rbase[AR];
+    unsigned rmask = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int m = m0 + r0 + 32 * i;
+        riy[i] = rix[i] = rbase[i] = 0;
+        if (m < g.M) {
+            uint32_t b = fdiv(m, g.div_ohw);
+            uint32_t rem = m - b * g.OHW;
+            uint32_t oy = fdiv(rem, g.div_ow);
+            uint32_t ox = rem - oy * g.OW;
+            riy[i] = oy * g.stride;
+            rix[i] = ox * g.stride;
+            rbase[i] = b * g.x_img_pitch;
+            rmask |= 1u << i;
+        }
+    }
+    const size_t wrow = (size_t)(n0 + r0) * a.w_ld;
+
+    u32x4 ra[AR], rb[BR];
+    auto load_tile = [&](int ks) {
+        const int k0 = ks * BK + cc * VEC;
+        const bool kv = k0 < g.Kvalid;
+        int tap = 0, c = k0;
+        if (g.cin_log2 >= 0) { tap = k0 >> g.cin_log2; c = k0 & (g.Cin - 1); }
+        int dy, dx;
+        tap_offset(g, tap, dy, dx);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int iy = riy[i] + dy, ix = rix[i] + dx;
+            bool ok = kv && ((rmask >> i) & 1u);
+            ok = pad_coord(g, iy, ix) && ok;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *(const u32x4*)(xp + ((size_t)rbase[i] + (size_t)(iy * g.x_row_pitch + ix * g.x_pix_pitch + c)));
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = *(const u32x4*)(wp + wrow + (size_t)(32 * i) * a.w_ld + (ks * BK + cc * VEC));
+    };
+    auto store_tile = [&](int buf) {
+        char* As = smem + buf * STAGE;
+        char* Ws = As + BM * PITCH;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *(u32x4*)(As + (r0 + 32 * i) * PITCH + cc * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *(u32x4*)(Ws + (r0 + 32 * i) * PITCH + cc * 16) = rb[i];
+    };
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    const int ks_beg = blockIdx.z * a.nk_per_split;
+    const int ks_end = min(a.nk_total, ks_beg + a.nk_per_split);
+
+    if (ks_beg < ks_end) {
+        load_tile(ks_beg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int ks = ks_beg; ks < ks_end; ++ks) {
+        const int buf = (ks - ks_beg) & 1;
+        const bool more = ks + 1 < ks_end;
+        if (more) load_tile(ks + 1);
+        const char* As = smem + buf * STAGE;
+        const char* Ws = As + BM * PITCH;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int koff = (kk * 16 + 8 * h) * (int)sizeof(T);
+            frag wf[NI], xf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                wf[ni] = *(const frag*)(Ws + (wn * WTN + ni * 32 + l31) * PITCH + koff);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                xf[mi] = *(const frag*)(As + (wm * WTM + mi * 32 + l31) * PITCH + koff);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wf[ni], xf[mi]);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = n][col = m]; lane owns pixel column l31, 4 consecutive n per register group
+    T* __restrict__ yp = (T*)a.y;
+    const T* __restrict__ resp = (const T*)a.res;
+    const T* __restrict__ gatep = (const T*)a.gate;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WTM + mi * 32 + l31;
+        if (m >= g.M) continue;
+        const uint32_t b = fdiv(m, g.div_ohw);
+        const uint32_t rem = m - b * g.OHW;
+        const uint32_t oy = fdiv(rem, g.div_ow);
+        const uint32_t ox = rem - oy * g.OW;
+        const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
+                            (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+        const float* cb = a.cbias ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WTN + ni * 32 + 8 * q + 4 * h;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j];
+                if (a.ksplit > 1) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(a.ws + ((size_t)blockIdx.z * g.M + m) * a.N + n) = o;
+                    continue;
+                }
+                if (a.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
+                }
+                if (cb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
+                }
+                if (resp) {
+                    float r[4];
+                    load4<T>(resp + yoff + n, r);
+                    if (gatep) {
+                        float gt[4];
+                        load4<T>(gatep + yoff + n, gt);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += r[j];
+                }
+                store4<T>(yp + yoff + n, v);
+            }
+        }
+    }
+}
+
+// split-K finish: y[m][n] = sum_z ws[z][m][n] + bias[n]   (dense rows of y_ld)
+template <typename T>
+__global__ void splitk_finish(const float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ bias,
+                              int M, int N, int y_ld, int ksplit) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over M * N/4
+    const int n4 = N / 4;
+    if (idx >= (int64_t)M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ksplit; ++z) s += *(const f32x4*)(ws + ((size_t)z * M + m) * N + n);
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    if (bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += bias[n + j];
+    }
+    store4<T>(y + (size_t)m * y_ld + n, v);
+}
+
+// ================================================================================
+// weight-gradient kernel
+// ================================================================================
+// LDS tiles keep the natural [pixel][channel] order; the MFMA operands need
+// [channel][8 consecutive pixels], i.e. a transpose.  bf16 uses the hardware
+// transposing read ds_read_b64_tr_b16: per 16-lane group it fetches a 4-pixel x
+// 16-channel block (lane 4q+p supplies the address of pixel q, channels 4p..4p+3)
+// and hands lane i channel i of the four pixels.  f32 reads single dwords.
+template <typename T> struct TrLoad;
+template <> struct TrLoad<bf16> {
+    __device__ static __forceinline__ bf16x8 ld(const char* base, int pitch, int m0, int c0, int lane) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, blk = (lane >> 4) & 1, h = lane >> 5;
+        const char* ptr = base + (m0 + 8 * h + q) * pitch + (c0 + 16 * blk + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)ptr);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(ptr + 4 * pitch));
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+        return r;
+    }
+};
+template <> struct TrLoad<float> {
+    __device__ static __forceinline__ f32x8 ld(const char* base, int pitch, int m0, int c0, int lane) {
+        const int l31 = lane & 31, h = lane >> 5;
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = *(const float*)(base + (m0 + 2 * j + h) * pitch + (c0 + l31) * 4);
+        return r;
+    }
+};
+// For T = float the slot (h, j) holds pixel 2j+h, for bf16 pixel 8h+j; both operands
+// of one MFMA use the same loader, so the products pair up correctly.
+
+template <typename T, int BNW, int BKW, int WN, int WK>
+__global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int BMS = 128 / (int)sizeof(T);                 // pixels per step: 64 bf16 / 32 f32
+    constexpr int PG = BNW * (int)sizeof(T) + 64, PA = BKW * (int)sizeof(T) + 64;
+    constexpr int CG = BNW / VEC, CA = BKW / VEC;             // 16-byte chunks per row
+    constexpr int RG = 256 / CG, RA = 256 / CA;               // rows covered per pass
+    constexpr int PGN = BMS / RG, PAN = BMS / RA;             // passes
+    constexpr int WTN = BNW / WN, WTK = BKW / WK, NI = WTN / 32, KI = WTK / 32;
+    constexpr int STAGE = BMS * (PG + PA);
+    typedef typename Elem<T>::frag frag;
+    static_assert(WN * WK == 4 && PGN >= 1 && PAN >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WK, wk = wave % WK;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BNW, kb0 = blockIdx.x * BKW;
+    const T* __restrict__ xp = (const T*)a.x;
+    const T* __restrict__ gp = (const T*)a.dy;
+
+    // dY chunk of this thread
+    const int ccg = tid % CG, rg0 = tid / CG;
+    const bool gcol_ok = n0 + ccg * VEC + VEC <= a.dy_ld;
+    // gathered-x chunk of this thread: k is fixed for the whole m loop
+    const int cca = tid % CA, ra0 = tid / CA;
+    const int k0 = kb0 + cca * VEC;
+    const bool kv = k0 < g.Kvalid;
+    int tap = 0, c = k0;
+    if (g.cin_log2 >= 0) { tap = k0 >> g.cin_log2; c = k0 & (g.Cin - 1); }
+    int dy, dx;
+    tap_offset(g, tap, dy, dx);
+
+    const int st_beg = blockIdx.z * a.steps_per_split;
+    const int st_end = min(a.nsteps_total, st_beg + a.steps_per_split);
+
+    u32x4 rgv[PGN], rav[PAN];
+    auto load_tile = [&](int st) {
+        const int mb = st * BMS;
+#pragma unroll
+        for (int i = 0; i < PGN; ++i) {
+            const int m = mb + rg0 + RG * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < g.M && gcol_ok) v = *(const u32x4*)(gp + (size_t)m * a.dy_ld + n0 + ccg * VEC);
+            rgv[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PAN; ++i) {
+            const int m = mb + ra0 + RA * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < g.M && kv) {
+                const uint32_t b = fdiv(m, g.div_ohw);
+                const uint32_t rem = m - b * g.OHW;
+                const uint32_t oy = fdiv(rem, g.div_ow);
+                const uint32_t ox = rem - oy * g.OW;
+                int iy = oy * g.stride + dy, ix = ox * g.stride + dx;
+                if (pad_coord(g, iy, ix))
+                    v = *(const u32x4*)(xp + ((size_t)b * g.x_img_pitch + (size_t)(iy * g.x_row_pitch + ix * g.x_pix_pitch + c)));
+            }
+            rav[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* Gs = smem + buf * STAGE;
+        char* As = Gs + BMS * PG;
+#pragma unroll
+        for (int i = 0; i < PGN; ++i) *(u32x4*)(Gs + (rg0 + RG * i) * PG + ccg * 16) = rgv[i];
+#pragma unroll
+        for (int i = 0; i < PAN; ++i) *(u32x4*)(As + (ra0 + RA * i) * PA + cca * 16) = rav[i];
+    };
+
+    f32x16 acc[NI][KI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][ki][r] = 0.f;
+
+    if (st_beg < st_end) {
+        load_tile(st_beg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int st = st_beg; st < st_end; ++st) {
+        const int buf = (st - st_beg) & 1;
+        const bool more = st + 1 < st_end;
+        if (more) load_tile(st + 1);
+        const char* Gs = smem + buf * STAGE;
+        const char* As = Gs + BMS * PG;
+#pragma unroll
+        for (int sub = 0; sub < BMS / 16; ++sub) {
+            frag gf[NI], af[KI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) gf[ni] = TrLoad<T>::ld(Gs, PG, sub * 16, wn * WTN + ni * 32, lane);
+#pragma unroll
+            for (int ki = 0; ki < KI; ++ki) af[ki] = TrLoad<T>::ld(As, PA, sub * 16, wk * WTK + ki * 32, lane);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int ki = 0; ki < KI; ++ki) mma32(acc[ni][ki], gf[ni], af[ki]);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partials: ws[z][n][k], D[row = n][col = k]
+    float* out = a.ws + (size_t)blockIdx.z * a.n_rows * a.k_ld;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki) {
+            const int k = kb0 + wk * WTK + ki * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * WTN + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)n * a.k_ld + k] = acc[ni][ki][r];
+            }
+        }
+}
+
+// ---- canonical <-> GEMM layout map ---------------------------------------------
+__device__ __forceinline__ int wmap_index(const cvg_wmap& m, int n, int k) {
+    if (n >= m.n_valid) return -1;
+    const int j = k / m.kd, c = k - j * m.kd;
+    if (c >= m.kc_valid || j >= m.ntaps) return -1;
+    int t = j;
+    if (m.tap_mode == 1) t = m.ntaps - 1 - j;
+    else if (m.tap_mode == 2) t = m.tap_table[j];
+    if (t < 0) return -1;
+    const int nq = n / m.nd, nr = n - nq * m.nd;
+    return nq * m.na + nr * m.nb + t * m.ka + c * m.kb;
+}
+
+__global__ void wgrad_reduce(const float* __restrict__ ws, float* __restrict__ grad, const cvg_wmap map,
+                             int n_rows, int k_ld, int nsplit, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)map.n_valid * k_ld) return;
+    const int n = (int)(idx / k_ld), k = (int)(idx % k_ld);
+    const int ci = wmap_index(map, n, k);
+    if (ci < 0) return;
+    float s = 0.f;
+    const size_t stride = (size_t)n_rows * k_ld;
+    const float* p = ws + (size_t)n * k_ld + k;
+    for (int z = 0; z < nsplit; ++z) s += p[z * stride];
+    grad[ci] = accumulate ? grad[ci] + s : s;
+}
+
+template <typename T>
+__global__ void weight_pack(const float* __restrict__ canonical, T* __restrict__ packed, const cvg_wmap map,
+                            int rows, int ld) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rows * ld) return;
+    const int n = (int)(idx / ld), k = (int)(idx % ld);
+    const int ci = wmap_index(map, n, k);
+    packed[idx] = from_f32<T>(ci >= 0 ? canonical[ci] : 0.f);
+}
+
+// ---- host side -------------------------------------------------------------------
+int elem_size(int dtype) { return dtype == CVG_BF16 ? 2 : 4; }
+
+int make_geom(const cvg_conv_desc* d, Geom& g) {
+    CVG_CHECK(d->dtype == CVG_F32 || d->dtype == CVG_BF16, "conv: bad dtype %d", d->dtype);
+    CVG_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0, "conv: bad dims");
+    CVG_CHECK(d->Cin > 0 && d->Cin % 8 == 0, "conv: Cin %d must be a multiple of 8", d->Cin);
+    CVG_CHECK(d->ntaps >= 1 && d->ntaps <= 64 && d->KW >= 1 && d->ntaps % d->KW == 0, "conv: bad taps");
+    g.cin_log2 = -1;
+    if (d->ntaps > 1) {
+        g.cin_log2 = ilog2_exact(d->Cin);
+        CVG_CHECK(g.cin_log2 >= 0, "conv: Cin %d must be a power of two when ntaps > 1", d->Cin);
+    }
+    const int64_t M = (int64_t)d->B * d->OH * d->OW;
+    CVG_CHECK(M < (1ll << 31), "conv: too many rows");
+    const int64_t x_elems = (int64_t)d->B * d->x_img_pitch;
+    CVG_CHECK(x_elems < (1ll << 31), "conv: gathered tensor too large for 32-bit offsets");
+    CVG_CHECK((d->x_pix_pitch * elem_size(d->dtype)) % 8 == 0 && d->x_row_pitch % 4 == 0 && d->x_img_pitch % 4 == 0,
+              "conv: pitches must keep 8-byte alignment");
+    if (d->pad_mode == CVG_PAD_REFLECT) {
+        // a mirrored coordinate must land inside the tensor after ONE reflection
+        const int kh = d->ntaps / d->KW;
+        int lo_y = d->off_y < (kh - 1) * d->tstep_y + d->off_y ? d->off_y : (kh - 1) * d->tstep_y + d->off_y;
+        int hi_y = (d->OH - 1) * d->stride + (d->off_y > (kh - 1) * d->tstep_y + d->off_y ? d->off_y : (kh - 1) * d->tstep_y + d->off_y);
+        int lo_x = d->off_x < (d->KW - 1) * d->tstep_x + d->off_x ? d->off_x : (d->KW - 1) * d->tstep_x + d->off_x;
+        int hi_x = (d->OW - 1) * d->stride + (d->off_x > (d->KW - 1) * d->tstep_x + d->off_x ? d->off_x : (d->KW - 1) * d->tstep_x + d->off_x);
+        CVG_CHECK(-lo_y < d->H && hi_y - (d->H - 1) < d->H && -lo_x < d->W && hi_x - (d->W - 1) < d->W,
+                  "conv: reflection padding wider than the tensor");
+    }
+    g.H = d->H; g.W = d->W; g.Cin = d->Cin;
+    g.x_img_pitch = d->x_img_pitch; g.x_row_pitch = d->x_row_pitch; g.x_pix_pitch = d->x_pix_pitch;
+    g.KW = d->KW; g.kw_inv = (65536 + d->KW - 1) / d->KW; g.ntaps = d->ntaps;
+    g.stride = d->stride; g.tstep_y = d->tstep_y; g.tstep_x = d->tstep_x;
+    g.off_y = d->off_y; g.off_x = d->off_x; g.pad_mode = d->pad_mode;
+    g.Kvalid = d->ntaps * d->Cin; g.M = (int)M; g.OW = d->OW; g.OHW = d->OH * d->OW;
+    g.div_ohw = make_fastdiv(g.OHW); g.div_ow = make_fastdiv(g.OW);
+    return 0;
+}
+
+int bk_of(int dtype) { return dtype == CVG_BF16 ? 64 : 32; }
+
+// split-K decision of the forward kernel (Linear layers with few output tiles)
+int fwd_ksplit(const cvg_conv_desc* d, int M, bool dense) {
+    const int BK = bk_of(d->dtype);
+    const int nk = ceil_div((int64_t)d->ntaps * d->Cin, BK);
+    const int tiles = ceil_div(M, 128) * ceil_div(d->N, 128);
+    if (!dense || tiles >= 64 || nk < 16) return 1;
+    int ks = 256 / tiles;
+    if (ks > nk / 4) ks = nk / 4;
+    if (ks > 64) ks = 64;
+    return ks < 1 ? 1 : ks;
+}
+bool fwd_dense_out(const cvg_conv_desc* d) {
+    return d->oy_mul == 1 && d->ox_mul == 1 && d->oy_off == 0 && d->ox_off == 0 &&
+           d->y_row_pitch == d->OW * d->y_pix_pitch && d->y_img_pitch == d->OH * d->y_row_pitch;
+}
+
+template <typename T>
+int launch_fwd(const cvg_conv_desc* d, FwdArgs& a, hipStream_t s) {
+    const int M = a.g.M, N = d->N;
+    dim3 blk(256);
+    if (N > 64) {
+        dim3 grid(ceil_div(M, 128), ceil_div(N, 128), a.ksplit);
+        igemm_fwd<T, 128, 128, 2, 2><<<grid, blk, 0, s>>>(a);
+    } else if (N > 32) {
+        dim3 grid(ceil_div(M, 256), 1, a.ksplit);
+        igemm_fwd<T, 256, 64, 4, 1><<<grid, blk, 0, s>>>(a);
+    } else {
+        dim3 grid(ceil_div(M, 256), 1, a.ksplit);
+        igemm_fwd<T, 256, 32, 4, 1><<<grid, blk, 0, s>>>(a);
+    }
+    CVG_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const int64_t n = (int64_t)M * (N / 4);
+        splitk_finish<T><<<ceil_div(n, 256), 256, 0, s>>>(a.ws, (T*)a.y, a.bias, M, N, d->y_pix_pitch, a.ksplit);
+        CVG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// weight-gradient tiling: output tile (BNW x BKW), pixels split over gridDim.z
+struct WgradPlan { int bnw, bkw, n_rows, k_ld, nsteps, nsplit, steps_per_split; };
+WgradPlan plan_wgrad(const cvg_conv_desc* d, int M) {
+    WgradPlan p;
+    p.bnw = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
+    p.bkw = 128;
+    p.n_rows = ceil_div(d->N, p.bnw) * p.bnw;
+    p.k_ld = ceil_div((int64_t)d->ntaps * d->Cin, p.bkw) * p.bkw;
+    const int bms = d->dtype == CVG_BF16 ? 64 : 32;
+    p.nsteps = ceil_div(M, bms);
+    const int tiles = (p.n_rows / p.bnw) * (p.k_ld / p.bkw);
+    int want = ceil_div(1024, tiles);
+    int maxs = p.nsteps / 4 > 0 ? p.nsteps / 4 : 1;
+    p.nsplit = want < maxs ? want : maxs;
+    if (p.nsplit > 512) p.nsplit = 512;
+    p.steps_per_split = ceil_div(p.nsteps, p.nsplit);
+    p.nsplit = ceil_div(p.nsteps, p.steps_per_split);
+    return p;
+}
+
+template <typename T>
+int launch_wgrad(const WgradPlan& p, WgradArgs& a, hipStream_t s) {
+    dim3 grid(p.k_ld / p.bkw, p.n_rows / p.bnw, p.nsplit), blk(256);
+    if (p.bnw == 128) igemm_wgrad<T, 128, 128, 2, 2><<<grid, blk, 0, s>>>(a);
+    else if (p.bnw == 64) igemm_wgrad<T, 64, 128, 2, 2><<<grid, blk, 0, s>>>(a);
+    else igemm_wgrad<T, 32, 128, 1, 4><<<grid, blk, 0, s>>>(a);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cvg_conv_fwd_workspace(const cvg_conv_desc* d) {
+    const int64_t M = (int64_t)d->B * d->OH * d->OW;
+    const int ks = fwd_ksplit(d, (int)M, fwd_dense_out(d));
+    return ks > 1 ? (size_t)ks * M * d->N * sizeof(float) : 0;
+}
+
+int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                 const float* cbias, const int32_t* labels, const void* res, const void* gate, void* ws,
+                 size_t ws_bytes, cvg_stream stream) {
+    FwdArgs a;
+    if (make_geom(d, a.g)) return -1;
+    const int BK = bk_of(d->dtype);
+    CVG_CHECK(d->N > 0 && d->N % 4 == 0, "conv_fwd: N %d must be a multiple of 4", d->N);
+    CVG_CHECK(d->w_ld % BK == 0 && d->w_ld >= a.g.Kvalid, "conv_fwd: w_ld %d does not cover K %d", d->w_ld, a.g.Kvalid);
+    CVG_CHECK(d->w_rows % 128 == 0 && d->w_rows >= d->N, "conv_fwd: w_rows %d must be N padded to 128", d->w_rows);
+    CVG_CHECK(x && w && y, "conv_fwd: null tensor");
+    CVG_CHECK(!cbias || labels, "conv_fwd: cbias needs labels");
+    CVG_CHECK(!gate || res, "conv_fwd: gate needs res");
+    CVG_CHECK(d->y_pix_pitch % 4 == 0 && d->y_row_pitch % 4 == 0 && d->y_img_pitch % 4 == 0, "conv_fwd: y pitches");
+    const bool dense = fwd_dense_out(d) && !res && !cbias;
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels; a.res = res; a.gate = gate;
+    a.ws = (float*)ws; a.N = d->N; a.w_ld = d->w_ld;
+    a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
+    a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
+    a.nk_total = ceil_div(a.g.Kvalid, BK);
+    a.ksplit = fwd_ksplit(d, a.g.M, dense);
+    a.nk_per_split = ceil_div(a.nk_total, a.ksplit);
+    a.ksplit = ceil_div(a.nk_total, a.nk_per_split);
+    if (a.ksplit > 1)
+        CVG_CHECK(ws && ws_bytes >= (size_t)a.ksplit * a.g.M * d->N * sizeof(float), "conv_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == CVG_BF16 ? launch_fwd<bf16>(d, a, s) : launch_fwd<float>(d, a, s);
+}
+
+size_t cvg_conv_wgrad_workspace(const cvg_conv_desc* d) {
+    const int64_t M = (int64_t)d->B * d->OH * d->OW;
+    WgradPlan p = plan_wgrad(d, (int)M);
+    return (size_t)p.nsplit * p.n_rows * p.k_ld * sizeof(float);
+}
+
+int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_t dy_ld, const cvg_wmap* map,
+                   float* grad, int32_t accumulate, void* ws, size_t ws_bytes, cvg_stream stream) {
+    WgradArgs a;
+    if (make_geom(d, a.g)) return -1;
+    CVG_CHECK(x && dy && map && grad && ws, "conv_wgrad: null tensor");
+    CVG_CHECK(dy_ld % 8 == 0 && dy_ld >= d->N, "conv_wgrad: dy_ld %d", dy_ld);
+    WgradPlan p = plan_wgrad(d, a.g.M);
+    CVG_CHECK(ws_bytes >= (size_t)p.nsplit * p.n_rows * p.k_ld * sizeof(float), "conv_wgrad: workspace too small");
+    CVG_CHECK(map->n_valid <= p.n_rows && map->kd > 0 && map->nd > 0, "conv_wgrad: bad map");
+    a.x = x; a.dy = dy; a.ws = (float*)ws; a.dy_ld = dy_ld; a.n_rows = p.n_rows; a.k_ld = p.k_ld;
+    a.nsteps_total = p.nsteps; a.steps_per_split = p.steps_per_split;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = d->dtype == CVG_BF16 ? launch_wgrad<bf16>(p, a, s) : launch_wgrad<float>(p, a, s);
+    if (rc) return rc;
+    const int64_t n = (int64_t)map->n_valid * p.k_ld;
+    wgrad_reduce<<<ceil_div(n, 256), 256, 0, s>>>(a.ws, grad, *map, p.n_rows, p.k_ld, p.nsplit, accumulate);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_weight_pack(const cvg_wmap* map, const float* canonical, void* packed, int32_t rows, int32_t ld,
+                    int32_t dtype, cvg_stream stream) {
+    CVG_CHECK(map && canonical && packed && rows > 0 && ld > 0, "weight_pack: bad args");
+    CVG_CHECK(map->kd > 0 && map->nd > 0, "weight_pack: bad map");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)rows * ld;
+    if (dtype == CVG_BF16) weight_pack<bf16><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (bf16*)packed, *map, rows, ld);
+    else weight_pack<float><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (float*)packed, *map, rows, ld);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

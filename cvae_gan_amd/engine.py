@@ -1,0 +1,634 @@
+"""The CVAE train-step executor for MI355X.
+
+Engine owns the canonical parameters (f32, reference layouts and checkpoint keys,
+models/cvae.py:234-235), their gradient / AdamW-moment arenas, the packed weight
+shadows and every activation buffer, and drives the HIP kernels stage by stage:
+
+    enc_forward -> sample -> dec_forward -> [loss] -> dec_backward ->
+    sample_backward -> enc_backward -> adamw
+
+Every stage only enqueues kernels on the current stream (no host sync), so a whole
+step can be captured into a HIP graph and replayed.
+
+Reference map (all in /root/reference):
+    enc_forward / enc_backward    models/networks.py:85-89, :164-196, :198-249
+    sample / sample_backward      models/networks.py:24-47, models/cvae.py:137
+    dec_forward / dec_backward    models/networks.py:63-68, :129-162, :263-281
+    losses                        models/cvae.py:137-140
+    adamw                         models/cvae.py:67, :157
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from ._lib import ConvDesc, WMap, PAD_ZERO, PAD_REFLECT
+
+EP = "encoder.module."
+DP = "decoder.module."
+ADAM_BETAS = (0.5, 0.999)        # models/cvae.py:67
+ADAM_EPS = 1e-8
+ADAM_WD = 1e-2                   # torch.optim.AdamW default
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+def stage_channels(n_stage, ngf):
+    out, prev = [], 1
+    for _ in range(n_stage):
+        cur = min(8, prev * 2)
+        out.append((ngf * prev, ngf * cur))
+        prev = cur
+    return out
+
+
+def up_channels(n_stage, ngf):
+    out, prev = [], 8
+    for i in range(n_stage - 1, -1, -1):
+        cur = min(prev, 2 ** i)
+        out.append((ngf * prev, ngf * cur))
+        prev = cur
+    return out
+
+
+def param_shapes(P, y_dim, z_dim, n_stage=4, ngf=64):
+    """Ordered {key: shape} of both checkpoints in state_dict order."""
+    def bn(d, prefix, c):
+        d[prefix + ".weight"] = (c,)
+        d[prefix + ".bias"] = (c,)
+        d[prefix + ".running_mean"] = (c,)
+        d[prefix + ".running_var"] = (c,)
+        d[prefix + ".num_batches_tracked"] = ()
+    enc = OrderedDict()
+    enc[EP + "conv.1.weight"] = (ngf, 3 + y_dim, 7, 7)
+    enc[EP + "conv.1.bias"] = (ngf,)
+    bn(enc, EP + "conv.2", ngf)
+    for i, (cin, cout) in enumerate(stage_channels(n_stage, ngf)):
+        p = EP + "conv.%d." % (4 + i)
+        enc[p + "res.res.0.weight"] = (cin, cin, 3, 3)
+        bn(enc, p + "res.res.1", cin)
+        enc[p + "res.res.3.weight"] = (cin, cin, 3, 3)
+        bn(enc, p + "res.res.4", cin)
+        enc[p + "conv.weight"] = (cout, cin, 3, 3)
+    s = P // (2 ** n_stage)
+    c_last = stage_channels(n_stage, ngf)[-1][1]
+    nz, fc_dim = 2 * z_dim, 4 * z_dim
+    enc[EP + "fc.0.weight"] = (fc_dim, s * s * c_last)
+    enc[EP + "fc.0.bias"] = (fc_dim,)
+    bn(enc, EP + "fc.1", fc_dim)
+    enc[EP + "fc.3.weight"] = (nz, fc_dim)
+    enc[EP + "fc.3.bias"] = (nz,)
+    dec = OrderedDict()
+    for i, (cin, cout) in enumerate(up_channels(n_stage, ngf)):
+        dec[DP + "conv.%d.2.weight" % i] = (cout, cin, 3, 3)
+        dec[DP + "conv.%d.2.bias" % i] = (cout,)
+    dec[DP + "conv.%d.weight" % (n_stage + 1)] = (3, ngf, 7, 7)
+    dec[DP + "conv.%d.bias" % (n_stage + 1)] = (3,)
+    in_dim = z_dim + y_dim
+    fcd = 4 * in_dim
+    dec[DP + "fc.0.weight"] = (fcd, in_dim)
+    dec[DP + "fc.0.bias"] = (fcd,)
+    dec[DP + "fc.3.weight"] = (s * s * ngf * 8, fcd)
+    dec[DP + "fc.3.bias"] = (s * s * ngf * 8,)
+    return enc, dec
+
+
+def is_buffer(key):
+    return key.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def init_state(P, y_dim, z_dim, seed=0, n_stage=4, ngf=64):
+    """init_weights(net, 'kaiming') semantics (models/networks.py:283-304): conv and
+    linear weights kaiming_normal_(a=0, fan_in), biases 0, BatchNorm2d gamma ~ N(1,.02),
+    BatchNorm1d untouched (gamma 1).  Host-side, once; returns CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    enc_s, dec_s = param_shapes(P, y_dim, z_dim, n_stage, ngf)
+    out = []
+    for shapes in (enc_s, dec_s):
+        sd = OrderedDict()
+        for k, shp in shapes.items():
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.zeros((), dtype=torch.long)
+            elif k.endswith("running_mean"):
+                sd[k] = torch.zeros(shp)
+            elif k.endswith("running_var"):
+                sd[k] = torch.ones(shp)
+            elif len(shp) >= 2:
+                fan_in = 1
+                for s_ in shp[1:]:
+                    fan_in *= s_
+                sd[k] = torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_in)
+            elif k.endswith(".bias"):
+                sd[k] = torch.zeros(shp)
+            else:
+                sd[k] = torch.ones(shp) if ".fc.1." in k else 1.0 + 0.02 * torch.randn(shp, generator=g)
+        out.append(sd)
+    return out[0], out[1]
+
+
+# ------------------------------------------------------------------------------------
+# descriptors
+# ------------------------------------------------------------------------------------
+def _desc(dtype, B, H, W, Cin, OH, OW, N, KW, ntaps, stride=1, tstep=(1, 1), off=(0, 0),
+          pad_mode=PAD_ZERO, x_pix=None, x_row=None, x_img=None, y_pix=None, y_row=None, y_img=None,
+          o_mul=(1, 1), o_off=(0, 0), y_dims=None):
+    d = ConvDesc()
+    d.dtype = ops.dt(dtype)
+    d.B, d.H, d.W, d.Cin = B, H, W, Cin
+    d.x_pix_pitch = x_pix if x_pix is not None else Cin
+    d.x_row_pitch = x_row if x_row is not None else W * d.x_pix_pitch
+    d.x_img_pitch = x_img if x_img is not None else H * d.x_row_pitch
+    d.OH, d.OW, d.N, d.KW, d.ntaps = OH, OW, N, KW, ntaps
+    d.stride = stride
+    d.tstep_y, d.tstep_x = tstep
+    d.off_y, d.off_x = off
+    d.pad_mode = pad_mode
+    yh, yw = y_dims if y_dims is not None else (OH, OW)
+    d.y_pix_pitch = y_pix if y_pix is not None else N
+    d.y_row_pitch = y_row if y_row is not None else yw * d.y_pix_pitch
+    d.y_img_pitch = y_img if y_img is not None else yh * d.y_row_pitch
+    d.oy_mul, d.ox_mul = o_mul
+    d.oy_off, d.ox_off = o_off
+    bk = 64 if dtype == torch.bfloat16 else 32
+    d.w_ld = _rup(ntaps * Cin, bk)
+    d.w_rows = _rup(N, 128)
+    return d
+
+
+def _wmap(nd, na, nb, kd, ka, kb, n_valid, kc_valid, ntaps, tap_mode=0, table=None):
+    m = WMap()
+    m.nd, m.na, m.nb, m.kd, m.ka, m.kb = nd, na, nb, kd, ka, kb
+    m.n_valid, m.kc_valid, m.ntaps, m.tap_mode = n_valid, kc_valid, ntaps, tap_mode
+    if table is not None:
+        assert len(table) <= 64
+        for i, t in enumerate(table):
+            m.tap_table[i] = t
+    return m
+
+
+class _Gemm:
+    """One packed-weight layout + the descriptor that consumes it."""
+
+    def __init__(self, eng, desc, wmap, canonical_key):
+        self.desc, self.wmap, self.key = desc, wmap, canonical_key
+        self.w = torch.zeros(desc.w_rows * desc.w_ld, dtype=eng.dtype, device=eng.device)
+        eng._gemms.append(self)
+        eng._ws_bytes = max(eng._ws_bytes, ops.conv_fwd_workspace(desc))
+
+    def pack(self, eng):
+        ops.weight_pack(self.wmap, eng.params[self.key], self.w, self.desc.w_rows, self.desc.w_ld)
+
+
+class Engine:
+    def __init__(self, pix_dim, y_dim, z_dim, batch, dtype=torch.bfloat16, ngf=64, n_stage=4,
+                 device="cuda", seed=0, state=None):
+        assert pix_dim % (2 ** n_stage) == 0, "pix_dim must be a multiple of %d" % (2 ** n_stage)
+        assert z_dim % 4 == 0, "z_dim must be a multiple of 4 (channel vectors are 8 wide)"
+        assert ngf % 8 == 0 and (ngf & (ngf - 1)) == 0, "ngf must be a power of two >= 8"
+        self.P, self.y, self.z, self.B = pix_dim, y_dim, z_dim, batch
+        self.dtype, self.ngf, self.n_stage = dtype, ngf, n_stage
+        self.device = torch.device(device)
+        self.s = pix_dim // (2 ** n_stage)
+        self._gemms, self._ws_bytes = [], 0
+        self.step_count = 0
+        self.training = True
+        self._build_params(seed, state)
+        self._build_encoder()
+        self._build_decoder()
+        self._build_workspaces()
+        self._packed_version = -1
+        self._param_version = 0
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self, seed, state):
+        enc_s, dec_s = param_shapes(self.P, self.y, self.z, self.n_stage, self.ngf)
+        self.enc_keys, self.dec_keys = list(enc_s), list(dec_s)
+        shapes = OrderedDict()
+        shapes.update(enc_s)
+        shapes.update(dec_s)
+        self.shapes = shapes
+        # arena order = order in which backward finishes the gradients (decoder tail first,
+        # encoder stem last), so that contiguous ranges can be all-reduced while backward runs
+        trainable = [k for k in shapes if not is_buffer(k)]
+        dec_tr = [k for k in trainable if k.startswith(DP)]
+        enc_tr = [k for k in trainable if k.startswith(EP)]
+
+        def dec_rank(k):
+            if ".fc.0." in k:
+                return 100
+            if ".fc.3." in k:
+                return 99
+            return self.n_stage + 1 - int(k[len(DP) + 5:].split(".")[0])      # conv.N...
+
+        def enc_rank(k):
+            if ".fc." in k:
+                return 3 - int(k.split(".fc.")[1].split(".")[0])
+            return 100 - int(k[len(EP) + 5:].split(".")[0])
+
+        order = sorted(dec_tr, key=dec_rank) + sorted(enc_tr, key=enc_rank)
+        self.arena_order = order
+        offs, n = {}, 0
+        for k in order:
+            offs[k] = n
+            n += _rup(int(torch.Size(shapes[k]).numel()), 4)
+        self.arena_offsets, self.arena_numel = offs, n
+        dev = self.device
+        self.p_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.g_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.params, self.grads, self.buffers = OrderedDict(), OrderedDict(), OrderedDict()
+        for k in shapes:
+            if is_buffer(k):
+                continue
+            cnt = int(torch.Size(shapes[k]).numel())
+            self.params[k] = self.p_arena[offs[k]:offs[k] + cnt].view(shapes[k])
+            self.grads[k] = self.g_arena[offs[k]:offs[k] + cnt].view(shapes[k])
+        for k in shapes:
+            if is_buffer(k):
+                self.buffers[k] = torch.zeros(shapes[k], device=dev,
+                                              dtype=torch.long if k.endswith("tracked") else torch.float32)
+        if state is None:
+            e, d = init_state(self.P, self.y, self.z, seed, self.n_stage, self.ngf)
+            state = OrderedDict(e)
+            state.update(d)
+        self.load_state(state)
+
+    def load_state(self, state):
+        """Copy reference-layout tensors (either checkpoint's keys) into the engine."""
+        with torch.no_grad():
+            for k, v in state.items():
+                if k in self.params:
+                    assert tuple(v.shape) == tuple(self.shapes[k]), (k, tuple(v.shape), self.shapes[k])
+                    self.params[k].copy_(v.to(torch.float32))
+                elif k in self.buffers:
+                    self.buffers[k].copy_(v)
+                else:
+                    raise KeyError("unexpected key %r" % k)
+        self._param_version = getattr(self, "_param_version", 0) + 1
+
+    def state_dict(self, which):
+        """'encoder' / 'decoder' checkpoint dict with the reference's keys, on the CPU."""
+        keys = self.enc_keys if which == "encoder" else self.dec_keys
+        out = OrderedDict()
+        for k in keys:
+            t = self.buffers[k] if is_buffer(k) else self.params[k]
+            out[k] = t.detach().cpu().clone()
+        return out
+
+    def params_changed(self):
+        """Call after writing to the canonical parameters from outside the engine."""
+        self._param_version += 1
+
+    # ------------------------------------------------------------------ layer plans
+    def _t(self, *shape):
+        return torch.zeros(*shape, dtype=self.dtype, device=self.device)
+
+    def _f(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def _conv3x3_plans(self, key, B, H, cin, cout, stride):
+        """zero-padded 3x3 conv (models/networks.py:246-249): forward, dgrad, wgrad."""
+        T = self.dtype
+        OH = H // stride
+        fwd = _Gemm(self, _desc(T, B, H, H, cin, OH, OH, cout, 3, 9, stride=stride, off=(-1, -1)),
+                    _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key)
+        if stride == 1:
+            dg = [_Gemm(self, _desc(T, B, H, H, cout, H, H, cin, 3, 9, off=(-1, -1)),
+                        _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key)]
+        else:
+            # transposed stride-2 conv split by output parity: rows 2a+py receive
+            # kh = 1 (from dY row a) when py = 0, kh = 0 (row a+1) and kh = 2 (row a) when py = 1
+            dg = []
+            for py in (0, 1):
+                for px in (0, 1):
+                    khs = [1] if py == 0 else [0, 2]
+                    kws = [1] if px == 0 else [0, 2]
+                    table = [kh * 3 + kw for kh in khs for kw in kws]
+                    d = _desc(T, B, OH, OH, cout, OH, OH, cin, len(kws), len(table),
+                              tstep=(-1, -1), off=(1 if py else 0, 1 if px else 0),
+                              o_mul=(2, 2), o_off=(py, px), y_dims=(H, H))
+                    dg.append(_Gemm(self, d, _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, len(table),
+                                                  tap_mode=2, table=table), key))
+        return fwd, dg
+
+    def _build_encoder(self):
+        B, P, ngf, T = self.B, self.P, self.ngf, self.dtype
+        e = self.enc = {}
+        # stem: reflection-padded NHWC4 image, 7 row-taps of 8 pixels x 4 channels (kw = 7 and
+        # channel 3 carry zero weights); label planes folded into a per-class bias
+        Hp, Wp = P + 6, P + 8
+        table = [(kh * 7 + kw) if kw < 7 else -1 for kh in range(7) for kw in range(8)]
+        e["stem"] = _Gemm(self, _desc(T, B, Hp, Wp, 32, P, P, ngf, 1, 7, x_pix=4),
+                          _wmap(1, (3 + self.y) * 49, 0, 4, 1, 49, ngf, 3, 56, tap_mode=2, table=table),
+                          EP + "conv.1.weight")
+        e["xpad"] = self._t(B, Hp, Wp, 4)
+        e["cbias"] = self._f(self.y, ngf)
+        e["s0"] = self._t(B * P * P, ngf)
+        e["a0"] = self._t(B * P * P, ngf)
+        e["st0"] = self._f(2, ngf)
+        e["d_a0"] = self._t(B * P * P, ngf)
+        e["d_s0"] = self._t(B * P * P, ngf)
+        e["blocks"] = []
+        H = P
+        for i, (cin, cout) in enumerate(stage_channels(self.n_stage, ngf)):
+            p = EP + "conv.%d." % (4 + i)
+            M = B * H * H
+            blk = {"prefix": p, "H": H, "cin": cin, "cout": cout, "M": M}
+            blk["conv1"], blk["dg1"] = self._conv3x3_plans(p + "res.res.0.weight", B, H, cin, cin, 1)
+            blk["conv2"], blk["dg2"] = self._conv3x3_plans(p + "res.res.3.weight", B, H, cin, cin, 1)
+            blk["down"], blk["dgd"] = self._conv3x3_plans(p + "conv.weight", B, H, cin, cout, 2)
+            for name in ("c1", "b1", "c2", "r", "d_r", "d_c2", "d_b1", "d_c1"):
+                blk[name] = self._t(M, cin)
+            blk["st1"], blk["st2"] = self._f(2, cin), self._f(2, cin)
+            Mo = B * (H // 2) * (H // 2)
+            blk["out"] = self._t(Mo, cout)
+            blk["d_out"] = self._t(Mo, cout)
+            e["blocks"].append(blk)
+            H //= 2
+        s, C = self.s, stage_channels(self.n_stage, ngf)[-1][1]
+        fin, fcd, nz = s * s * C, 4 * self.z, 2 * self.z
+        e["fin"], e["fcd"], e["nz"], e["C_last"] = fin, fcd, nz, C
+        # Linear layers as 1x1 "convolutions" over a 1x1 image; the flatten order of the
+        # reference is (c, h, w), ours (h, w, c): the weight maps carry the permutation.
+        e["fc0"] = _Gemm(self, _desc(T, B, 1, 1, fin, 1, 1, fcd, 1, 1),
+                         _wmap(1, fin, 0, C, 1, s * s, fcd, C, s * s), EP + "fc.0.weight")
+        e["fc0_dg"] = _Gemm(self, _desc(T, B, 1, 1, fcd, 1, 1, fin, 1, 1),
+                            _wmap(C, 1, s * s, fcd, 0, fin, fin, fcd, 1), EP + "fc.0.weight")
+        e["fc3"] = _Gemm(self, _desc(T, B, 1, 1, fcd, 1, 1, nz, 1, 1),
+                         _wmap(1, fcd, 0, fcd, 0, 1, nz, fcd, 1), EP + "fc.3.weight")
+        e["fc3_dg"] = _Gemm(self, _desc(T, B, 1, 1, nz, 1, 1, fcd, 1, 1),
+                            _wmap(1, 1, 0, nz, 0, fcd, fcd, nz, 1), EP + "fc.3.weight")
+        e["f0"], e["f1"] = self._t(B, fcd), self._t(B, fcd)
+        e["d_f0"], e["d_f1"] = self._t(B, fcd), self._t(B, fcd)
+        e["stf"] = self._f(2, fcd)
+        e["h"] = self._t(B, nz)
+        e["dh"] = self._t(B, nz)
+        e["labels"] = torch.zeros(B, dtype=torch.int32, device=self.device)
+
+    def _build_decoder(self):
+        B, P, ngf, T, s = self.B, self.P, self.ngf, self.dtype, self.s
+        d = self.dec = {}
+        C0 = ngf * 8
+        zin_ld = _rup(self.z + self.y, 8)
+        F = 4 * (self.z + self.y)
+        F8 = _rup(F, 8)
+        nout = s * s * C0
+        d.update(zin_ld=zin_ld, F=F, F8=F8, nout=nout, C0=C0)
+        d["zin"] = self._t(B, zin_ld)
+        d["dzin"] = self._t(B, zin_ld)
+        d["fc0"] = _Gemm(self, _desc(T, B, 1, 1, zin_ld, 1, 1, F8, 1, 1),
+                         _wmap(1, self.z + self.y, 0, zin_ld, 0, 1, F, self.z + self.y, 1), DP + "fc.0.weight")
+        d["fc0_dg"] = _Gemm(self, _desc(T, B, 1, 1, F8, 1, 1, zin_ld, 1, 1),
+                            _wmap(1, 1, 0, F8, 0, self.z + self.y, self.z + self.y, F, 1), DP + "fc.0.weight")
+        d["fc3"] = _Gemm(self, _desc(T, B, 1, 1, F8, 1, 1, nout, 1, 1),
+                         _wmap(C0, F, s * s * F, F8, 0, 1, nout, F, 1), DP + "fc.3.weight")
+        d["fc3_dg"] = _Gemm(self, _desc(T, B, 1, 1, nout, 1, 1, F8, 1, 1),
+                            _wmap(1, 1, 0, C0, F, s * s * F, F, C0, s * s), DP + "fc.3.weight")
+        d["bias0"] = self._f(F8)
+        d["bias3"] = self._f(nout)
+        d["g0"], d["g1"] = self._t(B, F8), self._t(B, F8)
+        d["d_g0"], d["d_g1"] = self._t(B, F8), self._t(B, F8)
+        d["mask"] = torch.ones(B, F8, dtype=torch.uint8, device=self.device)
+        d["x0"] = self._t(B * s * s, C0)
+        d["d_x0"] = self._t(B * s * s, C0)
+        d["ups"] = []
+        h = s
+        for i, (cin, cout) in enumerate(up_channels(self.n_stage, ngf)):
+            key = DP + "conv.%d.2." % i
+            U = 2 * h + 2
+            up = {"key": key, "h": h, "cin": cin, "cout": cout}
+            # valid 3x3 conv on the up-sampled, reflection-padded tensor U
+            up["fwd"] = _Gemm(self, _desc(T, B, U, U, cin, 2 * h, 2 * h, cout, 3, 9),
+                              _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key + "weight")
+            # dU = full correlation of dY with the flipped kernel (zero padding 2)
+            up["dg"] = _Gemm(self, _desc(T, B, 2 * h, 2 * h, cout, U, U, cin, 3, 9, off=(-2, -2)),
+                             _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key + "weight")
+            up["u"] = self._t(B * U * U, cin)
+            up["d_u"] = self._t(B * U * U, cin)
+            up["y"] = self._t(B * 4 * h * h, cout)
+            up["d_y"] = self._t(B * 4 * h * h, cout)
+            d["ups"].append(up)
+            h *= 2
+        key = DP + "conv.%d." % (self.n_stage + 1)
+        d["tail_key"] = key
+        d["tail"] = _Gemm(self, _desc(T, B, P, P, ngf, P, P, 4, 7, 49, off=(-3, -3), pad_mode=PAD_REFLECT),
+                          _wmap(1, ngf * 49, 0, ngf, 1, 49, 3, ngf, 49), key + "weight")
+        d["tail_dg"] = _Gemm(self, _desc(T, B, P, P, 8, P + 6, P + 6, ngf, 7, 49, off=(-6, -6)),
+                             _wmap(1, 49, 0, 8, 1, ngf * 49, ngf, 3, 49, tap_mode=1), key + "weight")
+        d["tail_bias"] = self._f(4)
+        d["pre"] = self._t(B * P * P, 4)
+        d["dpre"] = self._t(B * P * P, 8)
+        d["dxp"] = self._t(B * (P + 6) * (P + 6), ngf)
+        d["dec"] = self._f(B, 3, P, P)
+        d["d_dec"] = self._f(B, 3, P, P)
+        d["bgrad8"] = self._f(8)
+        d["bgradF8"] = self._f(F8)
+        self.eps = self._f(B, self.z)
+        self.z_mean, self.z_sigma = self._f(B, self.z), self._f(B, self.z)
+        self.losses = self._f(4)          # [kl, ll, -, -]
+
+    def _build_workspaces(self):
+        wg = 0
+        for g in self._gemms:
+            wg = max(wg, ops.conv_wgrad_workspace(g.desc))
+        self.ws = torch.zeros(max(wg, self._ws_bytes, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
+        max_c = max(self.ngf * 8, self.dec["nout"], 4 * self.z, self.dec["F8"])
+        self.red_ws = torch.zeros(2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def pack_weights(self, force=False):
+        if not force and self._packed_version == self._param_version:
+            return
+        for g in self._gemms:
+            g.pack(self)
+        ops.label_bias(self.params[EP + "conv.1.weight"], self.enc["cbias"], self.ngf, self.y)
+        d = self.dec
+        ops.permute_f32(self.params[DP + "fc.0.bias"], d["bias0"], d["F"])
+        ops.permute_f32(self.params[DP + "fc.3.bias"], d["bias3"], d["nout"], d["C0"], 1, self.s * self.s)
+        ops.permute_f32(self.params[d["tail_key"] + "bias"], d["tail_bias"], 3)
+        self._packed_version = self._param_version
+
+    def _bn(self, x, res, y, M, C, stats, prefix):
+        if self.training:
+            ops.bn_stats(x, M, C, stats, self.buffers[prefix + ".running_mean"],
+                         self.buffers[prefix + ".running_var"], self.buffers[prefix + ".num_batches_tracked"],
+                         self.red_ws)
+        else:
+            ops.bn_eval_stats(self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"], C, stats)
+        ops.bn_act_fwd(x, res, y, M, C, stats, self.params[prefix + ".weight"], self.params[prefix + ".bias"])
+
+    def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix):
+        ops.bn_act_bwd(dy, y, x, dx, M, C, stats, self.params[prefix + ".weight"],
+                       self.grads[prefix + ".weight"], self.grads[prefix + ".bias"], self.red_ws)
+
+    def _fwd(self, g, x, y, bias=None, **kw):
+        ops.conv_fwd(g.desc, x, g.w, y, bias=bias, ws=self.ws, **kw)
+
+    def _wgrad(self, g, x, dy, dy_ld):
+        ops.conv_wgrad(g.desc, x, dy, dy_ld, g.wmap, self.grads[g.key], self.ws)
+
+    # ------------------------------------------------------------------ encoder
+    def enc_forward(self, x, labels):
+        """x: f32 NCHW [B,3,P,P] on the device; labels: int32 [B].  Returns h [B, 2z]."""
+        e, B, P, ngf = self.enc, self.B, self.P, self.ngf
+        self.pack_weights()
+        e["labels"].copy_(labels)
+        ops.pack_image(x, e["xpad"], B, P)
+        self._fwd(e["stem"], e["xpad"], e["s0"], bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],
+                  labels=e["labels"])
+        self._bn(e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2")
+        xin = e["a0"]
+        for blk in e["blocks"]:
+            p, M, C = blk["prefix"], blk["M"], blk["cin"]
+            self._fwd(blk["conv1"], xin, blk["c1"])
+            self._bn(blk["c1"], None, blk["b1"], M, C, blk["st1"], p + "res.res.1")
+            self._fwd(blk["conv2"], blk["b1"], blk["c2"])
+            self._bn(blk["c2"], xin, blk["r"], M, C, blk["st2"], p + "res.res.4")
+            self._fwd(blk["down"], blk["r"], blk["out"])
+            blk["xin"] = xin
+            xin = blk["out"]
+        self._fwd(e["fc0"], xin, e["f0"], bias=self.params[EP + "fc.0.bias"])
+        self._bn(e["f0"], None, e["f1"], B, e["fcd"], e["stf"], EP + "fc.1")
+        self._fwd(e["fc3"], e["f1"], e["h"], bias=self.params[EP + "fc.3.bias"])
+        return e["h"]
+
+    def enc_backward(self, dh):
+        e, B, P, ngf = self.enc, self.B, self.P, self.ngf
+        last = e["blocks"][-1]
+        self._wgrad(e["fc3"], e["f1"], dh, e["nz"])
+        ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws)
+        self._fwd(e["fc3_dg"], dh, e["d_f1"])
+        self._bn_bwd(e["d_f1"], e["f1"], e["f0"], e["d_f0"], B, e["fcd"], e["stf"], EP + "fc.1")
+        self._wgrad(e["fc0"], last["out"], e["d_f0"], e["fcd"])
+        ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws)
+        self._fwd(e["fc0_dg"], e["d_f0"], last["d_out"])
+        for i in range(len(e["blocks"]) - 1, -1, -1):
+            blk = e["blocks"][i]
+            p, M, C = blk["prefix"], blk["M"], blk["cin"]
+            self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
+            for g in blk["dgd"]:
+                self._fwd(g, blk["d_out"], blk["d_r"])
+            self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
+            self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
+            self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"])
+            self._bn_bwd(blk["d_b1"], blk["b1"], blk["c1"], blk["d_c1"], M, C, blk["st1"], p + "res.res.1")
+            self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
+            d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
+            # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
+            self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
+        self._bn_bwd(e["d_a0"], e["a0"], e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
+        self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
+        ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
+                           self.grads[EP + "conv.1.bias"], self.red_ws)
+
+    # ------------------------------------------------------------------ sampler
+    def sample(self, h, eps, batch_size):
+        d = self.dec
+        ops.reparam_kl_fwd(h, eps, self.enc["labels"], self.B, self.z, self.y, d["zin_ld"], d["zin"],
+                           self.z_mean, self.z_sigma, self.losses[0:1], batch_size)
+        return d["zin"]
+
+    def sample_backward(self, dzin, eps, g_mean, g_sigma, kl_scale, batch_size):
+        ops.reparam_kl_bwd(dzin, self.dec["zin_ld"], eps, self.z_mean, self.z_sigma, g_mean, g_sigma,
+                           kl_scale, batch_size, self.B, self.z, self.enc["dh"])
+        return self.enc["dh"]
+
+    def set_decoder_input(self, z, y_vec):
+        """zin = [z | y_vec | 0] from f32 tensors (decoder.forward's torch.cat, networks.py:64)."""
+        d = self.dec
+        buf = torch.zeros(self.B, d["zin_ld"], dtype=torch.float32, device=self.device)
+        buf[:, :self.z] = z
+        buf[:, self.z:self.z + self.y] = y_vec
+        ops.cast(buf, d["zin"], buf.numel())
+        return d["zin"]
+
+    # ------------------------------------------------------------------ decoder
+    def dec_forward(self, zin, mask=None):
+        """zin [B, zin_ld]; mask: uint8 keep mask [B, F8] (training) or None (eval).
+        Returns dec f32 NCHW [B,3,P,P]."""
+        d, B, P, s = self.dec, self.B, self.P, self.s
+        self.pack_weights()
+        self._fwd(d["fc0"], zin, d["g0"], bias=d["bias0"])
+        ops.lrelu_dropout_fwd(d["g0"], mask if self.training else None, d["g1"], B * d["F8"])
+        self._fwd(d["fc3"], d["g1"], d["x0"], bias=d["bias3"])
+        x = d["x0"]
+        for up in d["ups"]:
+            ops.upsample_pad_fwd(x, up["u"], B, up["h"], up["h"], up["cin"])
+            self._fwd(up["fwd"], up["u"], up["y"], bias=self.params[up["key"] + "bias"])
+            x = up["y"]
+        self._fwd(d["tail"], x, d["pre"], bias=d["tail_bias"])
+        ops.tanh_fwd(d["pre"], d["dec"], B, P)
+        return d["dec"]
+
+    def dec_backward(self, d_dec, mask=None):
+        d, B, P, s, ngf = self.dec, self.B, self.P, self.s, self.ngf
+        ops.tanh_bwd(d_dec, d["dec"], d["dpre"], B, P)
+        last = d["ups"][-1]
+        self._wgrad(d["tail"], last["y"], d["dpre"], 8)
+        ops.colsum(d["dpre"], B * P * P, 8, 8, d["bgrad8"], self.red_ws)
+        ops.permute_f32(d["bgrad8"], self.grads[d["tail_key"] + "bias"], 3)
+        self._fwd(d["tail_dg"], d["dpre"], d["dxp"])
+        ops.reflect_fold(d["dxp"], last["d_y"], B, P, P, ngf, 3)
+        for i in range(len(d["ups"]) - 1, -1, -1):
+            up = d["ups"][i]
+            M = B * 4 * up["h"] * up["h"]
+            self._wgrad(up["fwd"], up["u"], up["d_y"], up["cout"])
+            ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws)
+            self._fwd(up["dg"], up["d_y"], up["d_u"])
+            d_x = d["d_x0"] if i == 0 else d["ups"][i - 1]["d_y"]
+            ops.upsample_pad_bwd(up["d_u"], d_x, B, up["h"], up["h"], up["cin"])
+        self._wgrad(d["fc3"], d["g1"], d["d_x0"], d["nout"])
+        ops.colsum(d["d_x0"], B, d["nout"], d["nout"], self.grads[DP + "fc.3.bias"], self.red_ws,
+                   d["C0"], 1, s * s)
+        self._fwd(d["fc3_dg"], d["d_x0"], d["d_g1"])
+        ops.lrelu_dropout_bwd(d["d_g1"], d["g1"], mask if self.training else None, d["d_g0"], B * d["F8"])
+        self._wgrad(d["fc0"], d["zin"], d["d_g0"], d["F8"])
+        ops.colsum(d["d_g0"], B, d["F8"], d["F8"], d["bgradF8"], self.red_ws)
+        ops.permute_f32(d["bgradF8"], self.grads[DP + "fc.0.bias"], d["F"])
+        self._fwd(d["fc0_dg"], d["d_g0"], d["dzin"])
+        return d["dzin"]
+
+    # ------------------------------------------------------------------ fused step
+    def set_mask(self, keep):
+        """keep: [B, F] 0/1 tensor (any dtype) -> padded uint8 device mask."""
+        d = self.dec
+        d["mask"].zero_()
+        d["mask"][:, :d["F"]] = keep.to(self.device).to(torch.uint8)
+
+    def random_mask(self, seed):
+        d = self.dec
+        ops.dropout_mask(d["mask"], d["mask"].numel(), seed)
+
+    def forward_backward(self, x, labels, eps, batch_size, loss_scale=1.0):
+        """Forward + loss + backward of models/cvae.py:132-152 with every reduction on
+        the device.  x f32 NCHW, labels int32, eps f32 [B,z]; the dropout mask is the
+        one last set with set_mask()/random_mask().  Gradients land in self.grads;
+        self.losses = [KL, LL]."""
+        d = self.dec
+        h = self.enc_forward(x, labels)
+        zin = self.sample(h, eps, batch_size)
+        dec = self.dec_forward(zin, d["mask"])
+        ops.mse_fwd_bwd(dec, x, d["d_dec"], self.losses[1:2], dec.numel(), batch_size, loss_scale, self.red_ws)
+        dzin = self.dec_backward(d["d_dec"], d["mask"])
+        dh = self.sample_backward(dzin, eps, None, None, loss_scale, batch_size)
+        self.enc_backward(dh)
+        return dec
+
+    def adamw_step(self, lr, betas=ADAM_BETAS, eps=ADAM_EPS, weight_decay=ADAM_WD):
+        self.step_count += 1
+        ops.adamw(self.p_arena, self.g_arena, self.m_arena, self.v_arena, self.arena_numel, lr, betas[0],
+                  betas[1], eps, weight_decay, self.step_count)
+        self._param_version += 1
+
+    def train_step(self, x, labels, eps, batch_size, lr):
+        dec = self.forward_backward(x, labels, eps, batch_size)
+        self.adamw_step(lr)
+        return dec
+
+    def read_losses(self):
+        kl, ll = self.losses[:2].tolist()
+        return {"VAE": kl + ll, "KL": kl, "LL": ll}

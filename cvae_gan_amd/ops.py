@@ -1,0 +1,160 @@
+"""Thin torch-tensor wrappers over the C ABI (include/cvaegan.h).
+
+torch supplies device memory and the current HIP stream; every function here
+enqueues exactly the kernels of one C entry point on that stream."""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, ConvDesc, WMap, F32, BF16, PAD_ZERO, PAD_REFLECT  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    return _DT[d]
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "cvae_gan_amd ops need device tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def elt(dtype):
+    return 2 if dtype == torch.bfloat16 else 4
+
+
+def conv_fwd(desc, x, w, y, bias=None, cbias=None, labels=None, res=None, gate=None, ws=None):
+    check(lib.cvg_conv_fwd(C.byref(desc), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(cbias), ptr(labels),
+                           ptr(res), ptr(gate), ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0,
+                           stream()))
+
+
+def conv_fwd_workspace(desc):
+    return int(lib.cvg_conv_fwd_workspace(C.byref(desc)))
+
+
+def conv_wgrad(desc, x, dy, dy_ld, wmap, grad, ws, accumulate=False):
+    check(lib.cvg_conv_wgrad(C.byref(desc), ptr(x), ptr(dy), dy_ld, C.byref(wmap), ptr(grad), int(accumulate),
+                             ptr(ws), ws.numel() * ws.element_size(), stream()))
+
+
+def conv_wgrad_workspace(desc):
+    return int(lib.cvg_conv_wgrad_workspace(C.byref(desc)))
+
+
+def weight_pack(wmap, canonical, packed, rows, ld):
+    check(lib.cvg_weight_pack(C.byref(wmap), ptr(canonical), ptr(packed), rows, ld, dt(packed), stream()))
+
+
+def label_bias(w_stem, cbias, cout, y_dim):
+    check(lib.cvg_label_bias(ptr(w_stem), ptr(cbias), cout, y_dim, stream()))
+
+
+def label_bias_bwd(dy, labels, B, pixels, cout, y_dim, dw, dbias, ws):
+    check(lib.cvg_label_bias_bwd(ptr(dy), dt(dy), ptr(labels), B, pixels, cout, y_dim, ptr(dw), ptr(dbias),
+                                 ptr(ws), stream()))
+
+
+def pack_image(x, xpad, B, P):
+    check(lib.cvg_pack_image(ptr(x), ptr(xpad), B, P, dt(xpad), stream()))
+
+
+def bn_stats_blocks(M, C_):
+    return int(lib.cvg_bn_stats_blocks(M, C_))
+
+
+def bn_stats(x, M, C_, stats, running_mean, running_var, nbt, ws):
+    check(lib.cvg_bn_stats(ptr(x), dt(x), M, C_, ptr(stats), ptr(running_mean), ptr(running_var), ptr(nbt),
+                           ptr(ws), stream()))
+
+
+def bn_eval_stats(rm, rv, C_, stats):
+    check(lib.cvg_bn_eval_stats(ptr(rm), ptr(rv), C_, ptr(stats), stream()))
+
+
+def bn_act_fwd(x, res, y, M, C_, stats, gamma, beta):
+    check(lib.cvg_bn_act_fwd(ptr(x), ptr(res), ptr(y), dt(x), M, C_, ptr(stats), ptr(gamma), ptr(beta), stream()))
+
+
+def bn_act_bwd(dy, y, x, dx, M, C_, stats, gamma, dgamma, dbeta, ws):
+    check(lib.cvg_bn_act_bwd(ptr(dy), ptr(y), ptr(x), ptr(dx), dt(x), M, C_, ptr(stats), ptr(gamma),
+                             ptr(dgamma), ptr(dbeta), ptr(ws), stream()))
+
+
+def colsum(x, M, C_, ld, out, ws, map_d=1, map_a=1, map_b=0):
+    check(lib.cvg_colsum(ptr(x), dt(x), M, C_, ld, ptr(out), map_d, map_a, map_b, ptr(ws), stream()))
+
+
+def permute_f32(src, out, n, d=1, a=1, b=0):
+    check(lib.cvg_permute_f32(ptr(src), ptr(out), n, d, a, b, stream()))
+
+
+def reparam_kl_fwd(h, eps, labels, B, z, y_dim, zin_ld, zin, z_mean, z_sigma, kl, batch_size):
+    check(lib.cvg_reparam_kl_fwd(ptr(h), dt(h), ptr(eps), ptr(labels), B, z, y_dim, zin_ld, ptr(zin),
+                                 ptr(z_mean), ptr(z_sigma), ptr(kl), float(batch_size), stream()))
+
+
+def reparam_kl_bwd(dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, dh):
+    check(lib.cvg_reparam_kl_bwd(ptr(dzin), dt(dzin), zin_ld, ptr(eps), ptr(z_mean), ptr(z_sigma), ptr(g_mean),
+                                 ptr(g_sigma), float(kl_scale), float(batch_size), B, z, ptr(dh), stream()))
+
+
+def lrelu_dropout_fwd(x, mask, y, n):
+    check(lib.cvg_lrelu_dropout_fwd(ptr(x), ptr(mask), ptr(y), dt(x), n, stream()))
+
+
+def lrelu_dropout_bwd(dy, y, mask, dx, n):
+    check(lib.cvg_lrelu_dropout_bwd(ptr(dy), ptr(y), ptr(mask), ptr(dx), dt(y), n, stream()))
+
+
+def dropout_mask(mask, n, seed):
+    check(lib.cvg_dropout_mask(ptr(mask), n, seed, stream()))
+
+
+def upsample_pad_fwd(x, u, B, h, w, C_):
+    check(lib.cvg_upsample_pad_fwd(ptr(x), ptr(u), dt(x), B, h, w, C_, stream()))
+
+
+def upsample_pad_bwd(du, dx, B, h, w, C_):
+    check(lib.cvg_upsample_pad_bwd(ptr(du), ptr(dx), dt(du), B, h, w, C_, stream()))
+
+
+def reflect_fold(dxp, dx, B, H, W, C_, pad):
+    check(lib.cvg_reflect_fold(ptr(dxp), ptr(dx), dt(dxp), B, H, W, C_, pad, stream()))
+
+
+def tanh_fwd(pre, dec, B, P):
+    check(lib.cvg_tanh_fwd(ptr(pre), ptr(dec), dt(pre), B, P, stream()))
+
+
+def tanh_bwd(d_dec, dec, dpre, B, P):
+    check(lib.cvg_tanh_bwd(ptr(d_dec), ptr(dec), ptr(dpre), dt(dpre), B, P, stream()))
+
+
+def mse_fwd_bwd(dec, x, d_dec, ll, numel, batch_size, scale, ws):
+    check(lib.cvg_mse_fwd_bwd(ptr(dec), ptr(x), ptr(d_dec), ptr(ll), numel, float(batch_size), float(scale),
+                              ptr(ws), stream()))
+
+
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step):
+    check(lib.cvg_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, wd, step, stream()))
+
+
+def cast(src, out, n):
+    check(lib.cvg_cast(ptr(src), dt(src), ptr(out), dt(out), n, stream()))
+
+
+def nhwc_to_nchw(src, out, B, HW, C_, ld):
+    check(lib.cvg_nhwc_to_nchw(ptr(src), dt(src), ptr(out), B, HW, C_, ld, stream()))
+
+
+def nchw_to_nhwc(src, out, B, HW, C_, ld):
+    check(lib.cvg_nchw_to_nhwc(ptr(src), ptr(out), dt(out), B, HW, C_, ld, stream()))

@@ -1,0 +1,225 @@
+/* libcvaegan_hip.so -- C ABI of the MI355X (gfx950) kernels behind the CVAE train step.
+ *
+ * The reference (YuliangXiu/CVAE-GAN) has no FFI layer: every operation below
+ * replaces a torch.nn call made by models/networks.py or models/cvae.py, cited per
+ * entry point.  The Python host (cvae_gan_amd/) binds these with ctypes.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every pointer is DEVICE memory owned by the
+ *    caller; the library never allocates or frees device memory, never
+ *    synchronises, and enqueues only on the hipStream_t it is given.
+ *  - Return value 0 = enqueued; negative = rejected before any launch
+ *    (cvg_last_error() describes why).  No C++ exception crosses the boundary.
+ *  - dtype: CVG_F32 computes with exact-f32 MFMA (v_mfma_f32_32x32x2_f32);
+ *    CVG_BF16 stores activations / weight shadows as bf16 and accumulates in f32
+ *    (v_mfma_f32_32x32x16_bf16).  Statistics, losses, master weights, gradients
+ *    and optimiser state are f32 in both modes.
+ *  - Activations are NHWC ("pixel rows x channels"), channel counts multiples of 8.
+ */
+#ifndef CVAEGAN_H
+#define CVAEGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cvg_stream;            /* a hipStream_t */
+enum { CVG_F32 = 0, CVG_BF16 = 1 };
+enum { CVG_PAD_ZERO = 0, CVG_PAD_REFLECT = 1 };
+
+int         cvg_version(void);
+const char* cvg_last_error(void);
+
+/* ---- implicit-GEMM convolution geometry ----------------------------------------
+ * One descriptor covers every dense contraction of the step: Conv2d forward,
+ * its input gradient (a convolution of dY with re-laid-out weights), Linear layers
+ * (H = W = 1, one tap) and the weight gradient.  GEMM row m = (b, oy, ox) over
+ * OH x OW "output" pixels per image; GEMM column k = tap * Cin + c.
+ * Gathered input coordinate of (m, tap = ty * KW + tx):
+ *     iy = oy * stride + ty * tstep_y + off_y,   ix likewise,
+ * out-of-range coordinates read 0 (CVG_PAD_ZERO) or mirror (CVG_PAD_REFLECT).
+ * Output element (m, n) is stored at
+ *     y + b*y_img_pitch + (oy*oy_mul + oy_off)*y_row_pitch
+ *       + (ox*ox_mul + ox_off)*y_pix_pitch + n          (pitches in elements).    */
+typedef struct cvg_conv_desc {
+    int32_t dtype;
+    int32_t B, H, W;                 /* gathered tensor: images, rows, cols        */
+    int32_t Cin;                     /* k-extent per tap, multiple of 8; a power of
+                                        two when ntaps > 1                         */
+    int32_t x_img_pitch, x_row_pitch, x_pix_pitch;   /* elements                   */
+    int32_t OH, OW;                  /* GEMM-M pixels per image                    */
+    int32_t N;                       /* output channels stored (multiple of 4)     */
+    int32_t KW, ntaps;               /* taps per tap-row, total taps               */
+    int32_t stride, tstep_y, tstep_x, off_y, off_x;
+    int32_t pad_mode;
+    int32_t y_img_pitch, y_row_pitch, y_pix_pitch;
+    int32_t oy_mul, oy_off, ox_mul, ox_off;
+    int32_t w_ld;                    /* weight row length = K padded to 64 (bf16) / 32 (f32) */
+    int32_t w_rows;                  /* weight rows allocated (N padded to 128)    */
+} cvg_conv_desc;
+
+/* Conv2d / Linear forward and input-gradient.
+ * Replaces nn.Conv2d at models/networks.py:173, :246-249, :279-280, :148 and
+ * nn.Linear at :153, :156, :187, :190 (forward), and their autograd input
+ * gradients (models/cvae.py:152).
+ *   x      gathered activations (dtype)
+ *   w      weights [w_rows][w_ld] (dtype), row n = output channel, zero padded
+ *   y      output (dtype)
+ *   bias   f32 [N] or NULL
+ *   cbias  f32 [n_class][N] per-class bias or NULL; labels int32 [B]
+ *          (the encoder's one-hot label planes folded into the stem)
+ *   res    tensor added to the output, addressed like y, or NULL
+ *   gate   if non-NULL, res is scaled by (gate > 0 ? 1 : 0.2) elementwise
+ *          (LeakyReLU derivative read from the saved activation)
+ *   ws     f32 workspace of cvg_conv_fwd_workspace() bytes (split-K partials)    */
+size_t cvg_conv_fwd_workspace(const cvg_conv_desc* d);
+int    cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y,
+                    const float* bias, const float* cbias, const int32_t* labels,
+                    const void* res, const void* gate, void* ws, size_t ws_bytes,
+                    cvg_stream s);
+
+/* Weight gradient:  dWg[n][k] = sum_m dY[m][n] * gather(x)[m][k], then scattered to
+ * the canonical (reference-layout) f32 gradient through `map`.
+ * Replaces the weight-gradient half of autograd for the layers listed above.
+ *   dy     [M][dy_ld] (dtype), dense rows
+ *   grad   canonical f32 gradient tensor (OIHW conv / [out,in] linear)
+ *   accumulate != 0 adds into grad instead of overwriting                          */
+typedef struct cvg_wmap {
+    /* canonical index of GEMM-layout element (n, k):
+     *   (n / nd)*na + (n % nd)*nb + tap(k / kd)*ka + (k % kd)*kb
+     * tap(j) = j (tap_mode 0), ntaps-1-j (1) or tap_table[j] (2; -1 = structural zero).
+     * Elements with n >= n_valid, (k % kd) >= kc_valid or k / kd >= ntaps are zero. */
+    int32_t nd, na, nb, kd, ka, kb;
+    int32_t n_valid, kc_valid, ntaps, tap_mode;
+    int16_t tap_table[64];
+} cvg_wmap;
+
+size_t cvg_conv_wgrad_workspace(const cvg_conv_desc* d);
+int    cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_t dy_ld,
+                      const cvg_wmap* map, float* grad, int32_t accumulate,
+                      void* ws, size_t ws_bytes, cvg_stream s);
+
+/* Canonical f32 weights -> kernel layout [rows][ld] in dtype (rows >= n_valid, zero
+ * padded).  Runs once per optimiser step per layout.                              */
+int cvg_weight_pack(const cvg_wmap* map, const float* canonical, void* packed,
+                    int32_t rows, int32_t ld, int32_t dtype, cvg_stream s);
+
+/* Stem label fold (encoder.forward's torch.cat of label planes, networks.py:86,
+ * cvae.py:129): cbias[c][n] = sum over the 49 taps of W[n][3 + c][kh][kw].          */
+int cvg_label_bias(const float* w_stem, float* cbias, int32_t cout, int32_t y_dim,
+                   cvg_stream s);
+/* ... and its gradient: dW[n][3+c][*][*] = sum_{b: label[b]==c} S[b][n] where
+ * S[b][n] = sum_pixels dY[b][.][n]; db[n] = sum_b S[b][n].  ws: f32 [B][cout].      */
+int cvg_label_bias_bwd(const void* dy, int32_t dtype, const int32_t* labels, int32_t B,
+                       int32_t pixels, int32_t cout, int32_t y_dim, float* dw_stem,
+                       float* dbias, float* ws, cvg_stream s);
+
+/* ---- HBM-bound kernels ---------------------------------------------------------- */
+
+/* images NCHW f32 [B,3,P,P] -> reflection-padded NHWC4 [B][P+6][P+8][4] (dtype),
+ * channel 3 and the two extra columns are zero (nn.ReflectionPad2d(3), networks.py:172). */
+int cvg_pack_image(const float* x, void* xpad, int32_t B, int32_t P, int32_t dtype, cvg_stream s);
+
+/* Per-channel batch statistics of rows[M][C] (BatchNorm2d / BatchNorm1d training
+ * mode, networks.py:174, :235, :238, :188).  Writes stats = {mean[C], invstd[C]} and,
+ * if running_mean != NULL, updates running_mean / running_var (momentum 0.1,
+ * unbiased variance) and increments *num_batches_tracked (int64).
+ * ws: f32 [2][nblk][C] partials with nblk = cvg_bn_stats_blocks(M, C).              */
+int32_t cvg_bn_stats_blocks(int32_t M, int32_t C);
+int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
+                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                 float* ws, cvg_stream s);
+/* y = LeakyReLU_0.2( gamma * (x - mean) * invstd + beta  [+ res] ).
+ * eval mode: pass stats built from the running statistics (cvg_bn_eval_stats).   */
+int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32_t M, int32_t C,
+                   const float* stats, const float* gamma, const float* beta, cvg_stream s);
+int cvg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C,
+                      float* stats, cvg_stream s);
+/* Backward of the same: g = dy * (y > 0 ? 1 : 0.2);
+ * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
+ * The residual branch's gradient is g itself; consumers recompute it from (dy, y)
+ * through cvg_conv_fwd's res/gate arguments.  ws as for cvg_bn_stats.             */
+int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32_t dtype,
+                   int32_t M, int32_t C, const float* stats, const float* gamma,
+                   float* dgamma, float* dbeta, float* ws, cvg_stream s);
+
+/* Column sums of rows[M][ld] over the first C columns -> out[C] (bias gradients).
+ * out_map_d/a/b: out index of column c = (c / d)*a + (c % d)*b.                   */
+int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, float* out,
+               int32_t map_d, int32_t map_a, int32_t map_b, float* ws, cvg_stream s);
+
+/* out[i] = in[(i / d)*a + (i % d)*b]  (f32 gather; bias permutation for NHWC).   */
+int cvg_permute_f32(const float* in, float* out, int32_t n, int32_t d, int32_t a, int32_t b,
+                    cvg_stream s);
+
+/* CVAE_T._sample_latent + latent_loss (networks.py:24-47, cvae.py:137), fused.
+ *   h      [B][2z] (dtype) encoder head output
+ *   eps    f32 [B][z]
+ *   labels int32 [B]
+ *   zin    [B][zin_ld] (dtype): z, then the one-hot label, then zeros (decoder input,
+ *          networks.py:64)
+ *   z_mean, z_sigma  f32 [B][z]
+ *   kl     f32 scalar: mean(mu^2 + sigma^2 - log sigma^2 - 1) / batch_size         */
+int cvg_reparam_kl_fwd(const void* h, int32_t dtype, const float* eps, const int32_t* labels,
+                       int32_t B, int32_t z, int32_t y_dim, int32_t zin_ld, void* zin,
+                       float* z_mean, float* z_sigma, float* kl, float batch_size,
+                       cvg_stream s);
+/* dh[:, :z] = dz + g_mean + kl_scale*2*mu/(B*z*batch)
+ * dh[:, z:] = (dz*eps + g_sigma)*sigma + kl_scale*(2*sigma^2 - 2)/(B*z*batch)
+ * dz is read from dzin[B][zin_ld] (dtype); g_mean / g_sigma (f32, may be NULL) are
+ * gradients that arrive through the exposed z_mean / z_sigma tensors.              */
+int cvg_reparam_kl_bwd(const void* dzin, int32_t dtype, int32_t zin_ld, const float* eps,
+                       const float* z_mean, const float* z_sigma, const float* g_mean,
+                       const float* g_sigma, float kl_scale, float batch_size, int32_t B,
+                       int32_t z, void* dh, cvg_stream s);
+
+/* LeakyReLU(0.2) followed by Dropout(0.5) with an explicit keep mask (uint8, 1 = keep,
+ * kept values x2) -- networks.py:154-155.  mask == NULL: eval mode (identity dropout). */
+int cvg_lrelu_dropout_fwd(const void* x, const uint8_t* mask, void* y, int32_t dtype,
+                          int64_t n, cvg_stream s);
+int cvg_lrelu_dropout_bwd(const void* dy, const void* y, const uint8_t* mask, void* dx,
+                          int32_t dtype, int64_t n, cvg_stream s);
+/* Device-side keep mask: counter-based hash of (seed, index), p_keep = 0.5.        */
+int cvg_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, cvg_stream s);
+
+/* Interpolate(x2, bilinear, align_corners=False) + ReflectionPad2d(1)
+ * (networks.py:277-278): x [B][h][w][C] -> u [B][2h+2][2w+2][C]; and the transpose. */
+int cvg_upsample_pad_fwd(const void* x, void* u, int32_t dtype, int32_t B, int32_t h, int32_t w,
+                         int32_t C, cvg_stream s);
+int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int32_t h, int32_t w,
+                         int32_t C, cvg_stream s);
+
+/* Transpose of ReflectionPad2d(pad): dxp [B][H+2p][W+2p][C] -> dx [B][H][W][C].     */
+int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_t H, int32_t W,
+                     int32_t C, int32_t pad, cvg_stream s);
+
+/* nn.Tanh on the tail conv output (networks.py:149): pre [B*P*P][4] (dtype) ->
+ * dec NCHW f32 [B][3][P][P]; backward d_dec NCHW f32 -> dpre [B*P*P][8] (dtype).   */
+int cvg_tanh_fwd(const void* pre, float* dec, int32_t dtype, int32_t B, int32_t P, cvg_stream s);
+int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, int32_t dtype, int32_t B,
+                 int32_t P, cvg_stream s);
+/* Reconstruction loss of models/cvae.py:139: ll = 50 * mean((dec - x)^2) / batch_size,
+ * and d_dec = scale * 100 * (dec - x) / (numel * batch_size).                       */
+int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, int64_t numel,
+                    float batch_size, float scale, float* ws, cvg_stream s);
+
+/* torch.optim.AdamW(betas=(0.5, 0.999), eps=1e-8, weight_decay=0.01) over one flat
+ * f32 arena (models/cvae.py:67, :157).  step counts from 1.                         */
+int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, int32_t step, cvg_stream s);
+
+/* f32 <-> dtype copies of dense buffers (module-boundary conversions).             */
+int cvg_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n,
+             cvg_stream s);
+/* NHWC (dtype) [B][HW][C] <-> NCHW f32 [B][C][HW] (test / export helper).           */
+int cvg_nhwc_to_nchw(const void* in, int32_t dtype, float* out, int32_t B, int32_t HW, int32_t C,
+                     int32_t ld, cvg_stream s);
+int cvg_nchw_to_nhwc(const float* in, void* out, int32_t dtype, int32_t B, int32_t HW, int32_t C,
+                     int32_t ld, cvg_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVAEGAN_H */

@@ -226,9 +226,11 @@ def encoder_forward(sd, x, planes, train=True, new_stats=None, taps=None, n_stag
         if taps is not None:
             taps["block%d" % i] = t
     h = h.reshape(h.shape[0], -1)
-    h = F.linear(h, sd[EP + "fc.0.weight"], sd[EP + "fc.0.bias"])
-    h = _lrelu(_bn(sd, EP + "fc.1", h, train, new_stats))
-    return F.linear(h, sd[EP + "fc.3.weight"], sd[EP + "fc.3.bias"])
+    f0 = F.linear(h, sd[EP + "fc.0.weight"], sd[EP + "fc.0.bias"])
+    f1 = _lrelu(_bn(sd, EP + "fc.1", f0, train, new_stats))
+    if taps is not None:
+        taps.update(f0=f0, f1=f1)
+    return F.linear(f1, sd[EP + "fc.3.weight"], sd[EP + "fc.3.bias"])
 
 
 def sample_latent(h_enc, eps, z_dim):
@@ -260,19 +262,27 @@ def decoder_forward(sd, z, y_vec, drop_mask=None, train=True, taps=None, n_stage
     (models/networks.py:155); kept activations are scaled by 2.  In eval mode the
     dropout is the identity."""
     h = torch.cat([z, y_vec], dim=1)
-    h = _lrelu(F.linear(h, sd[DP + "fc.0.weight"], sd[DP + "fc.0.bias"]))
+    g0 = F.linear(h, sd[DP + "fc.0.weight"], sd[DP + "fc.0.bias"])
+    h = _lrelu(g0)
     if train:
         h = h * drop_mask * 2.0
+    g1 = h
     h = F.linear(h, sd[DP + "fc.3.weight"], sd[DP + "fc.3.bias"])
+    if taps is not None:
+        taps.update(g0=g0, g1=g1)
     c0 = sd[DP + "conv.0.2.weight"].shape[1]
     s = int(round(math.sqrt(h.shape[1] // c0)))
     h = h.view(h.shape[0], c0, s, s)
+    if taps is not None:
+        taps["x0"] = h
     for i in range(n_stage):
         h = upconv(sd, DP + "conv.%d.2." % i, h)
         if taps is not None:
             taps["up%d" % i] = h
     k = DP + "conv.%d." % (n_stage + 1)
     h = F.conv2d(F.pad(h, (3, 3, 3, 3), mode="reflect"), sd[k + "weight"], sd[k + "bias"])
+    if taps is not None:
+        taps["pre"] = h
     return torch.tanh(h)
 
 

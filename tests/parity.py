@@ -1,0 +1,159 @@
+"""Layer-by-layer comparison of the HIP engine against the CPU oracle.
+
+run_parity() replays one golden case through both and returns, for every forward
+activation, every activation gradient and every parameter gradient, the error of
+the HIP path relative to the largest reference magnitude of that tensor.  The
+pytest GPU tests put thresholds on these numbers; tools/gpu_diag.py prints them."""
+from collections import OrderedDict
+
+import torch
+
+from oracle import ref_cpu as O
+from helpers import Case
+
+
+def nchw(t, B, H, W, C, ld=None):
+    """engine rows [B*H*W][ld] -> f32 NCHW on the CPU"""
+    ld = ld or C
+    return t.detach().float().view(B, H, W, ld)[..., :C].permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel_err(got, ref):
+    ref = ref.detach().double()
+    got = got.detach().double()
+    if got.shape != ref.shape:
+        return float("inf"), float(ref.abs().max())
+    den = float(ref.abs().max())
+    return float((got - ref).abs().max()) / (den if den > 0 else 1.0), den
+
+
+def cosine(got, ref):
+    a, b = got.detach().double().flatten(), ref.detach().double().flatten()
+    d = float(a.norm() * b.norm())
+    return float((a * b).sum()) / d if d > 0 else 1.0
+
+
+def oracle_pass(case, step=0, state=None):
+    """Forward + backward of the oracle with every intermediate retained."""
+    e, d = state if state is not None else case.init_state()
+    x, labels, eps, mask = case.inputs(step)
+    params = {}
+    for sd in (e, d):
+        for k, t in sd.items():
+            if not O.is_buffer(k):
+                sd[k] = t.detach().clone().requires_grad_(True)
+                params[k] = sd[k]
+    et, dt = {}, {}
+    new_stats = {}
+    planes = O.label_planes(labels, case.y, case.P)
+    h = O.encoder_forward(e, x, planes, True, new_stats, et)
+    z, mu, sigma = O.sample_latent(h, eps, case.z)
+    dec = O.decoder_forward(d, z, O.one_hot(labels, case.y), mask, True, dt)
+    vae, kl, ll = O.losses(dec, x, mu, sigma, case.bs_flag)
+    acts = OrderedDict()
+    acts["s0"] = et["stem"]
+    acts["a0"] = et["a0"]
+    for i in range(4):
+        b = et["block%d" % i]
+        for n in ("c1", "b1", "c2", "r", "out"):
+            acts["blk%d.%s" % (i, n)] = b[n]
+    acts["f0"], acts["f1"], acts["h"] = et["f0"], et["f1"], h
+    acts["g0"], acts["g1"], acts["x0"] = dt["g0"], dt["g1"], dt["x0"]
+    for i in range(4):
+        acts["up%d" % i] = dt["up%d" % i]
+    acts["pre"], acts["dec"] = dt["pre"], dec
+    for t in acts.values():
+        t.retain_grad()
+    vae.backward()
+    agrads = OrderedDict((k, t.grad) for k, t in acts.items() if t.grad is not None)
+    pgrads = OrderedDict((k, p.grad) for k, p in params.items())
+    return dict(acts=acts, agrads=agrads, pgrads=pgrads, losses=dict(VAE=vae, KL=kl, LL=ll),
+                z_mean=mu, z_sigma=sigma, new_stats=new_stats)
+
+
+def engine_pass(case, dtype, step=0):
+    from cvae_gan_amd.engine import Engine
+    e, d = case.init_state()
+    st = OrderedDict(e)
+    st.update(d)
+    eng = Engine(case.P, case.y, case.z, case.B, dtype=dtype, ngf=case.ngf, state=st)
+    x, labels, eps, mask = case.inputs(step)
+    eng.set_mask(mask)
+    xd = x.cuda()
+    eng.forward_backward(xd, labels.int().cuda(), eps.cuda(), float(case.bs_flag))
+    torch.cuda.synchronize()
+    return eng
+
+
+def engine_tensors(eng):
+    B, P, ngf, s = eng.B, eng.P, eng.ngf, eng.s
+    e, d = eng.enc, eng.dec
+    acts, agrads = OrderedDict(), OrderedDict()
+    acts["s0"] = nchw(e["s0"], B, P, P, ngf)
+    acts["a0"] = nchw(e["a0"], B, P, P, ngf)
+    agrads["s0"] = nchw(e["d_s0"], B, P, P, ngf)
+    agrads["a0"] = nchw(e["d_a0"], B, P, P, ngf)
+    for i, blk in enumerate(e["blocks"]):
+        H, C, Co = blk["H"], blk["cin"], blk["cout"]
+        for n in ("c1", "b1", "c2", "r"):
+            acts["blk%d.%s" % (i, n)] = nchw(blk[n], B, H, H, C)
+            agrads["blk%d.%s" % (i, n)] = nchw(blk["d_" + n], B, H, H, C)
+        acts["blk%d.out" % i] = nchw(blk["out"], B, H // 2, H // 2, Co)
+        agrads["blk%d.out" % i] = nchw(blk["d_out"], B, H // 2, H // 2, Co)
+    acts["f0"], acts["f1"], acts["h"] = e["f0"].float().cpu(), e["f1"].float().cpu(), e["h"].float().cpu()
+    agrads["f0"], agrads["f1"], agrads["h"] = e["d_f0"].float().cpu(), e["d_f1"].float().cpu(), e["dh"].float().cpu()
+    F = d["F"]
+    acts["g0"], acts["g1"] = d["g0"].float().cpu()[:, :F], d["g1"].float().cpu()[:, :F]
+    agrads["g0"], agrads["g1"] = d["d_g0"].float().cpu()[:, :F], d["d_g1"].float().cpu()[:, :F]
+    acts["x0"] = nchw(d["x0"], B, s, s, d["C0"])
+    agrads["x0"] = nchw(d["d_x0"], B, s, s, d["C0"])
+    for i, up in enumerate(d["ups"]):
+        hh = 2 * up["h"]
+        acts["up%d" % i] = nchw(up["y"], B, hh, hh, up["cout"])
+        agrads["up%d" % i] = nchw(up["d_y"], B, hh, hh, up["cout"])
+    acts["pre"] = nchw(d["pre"], B, P, P, 3, 4)
+    agrads["pre"] = nchw(d["dpre"], B, P, P, 3, 8)
+    acts["dec"] = d["dec"].cpu()
+    agrads["dec"] = d["d_dec"].cpu()
+    pgrads = OrderedDict((k, g.detach().cpu().clone()) for k, g in eng.grads.items())
+    return acts, agrads, pgrads
+
+
+def run_parity(name, dtype, step=0):
+    """-> list of (kind, key, rel_err, ref_max, cosine)"""
+    case = Case(name)
+    ref = oracle_pass(case, step)
+    eng = engine_pass(case, dtype, step)
+    acts, agrads, pgrads = engine_tensors(eng)
+    rows = []
+    for k, t in ref["acts"].items():
+        r, m = rel_err(acts[k], t)
+        rows.append(("act", k, r, m, cosine(acts[k], t)))
+    for k in reversed(list(ref["agrads"].keys())):
+        r, m = rel_err(agrads[k], ref["agrads"][k])
+        rows.append(("dact", k, r, m, cosine(agrads[k], ref["agrads"][k])))
+    for k in eng.arena_order:
+        r, m = rel_err(pgrads[k], ref["pgrads"][k])
+        rows.append(("grad", k, r, m, cosine(pgrads[k], ref["pgrads"][k])))
+    got = eng.read_losses()
+    for k in ("VAE", "KL", "LL"):
+        rv = float(ref["losses"][k])
+        rows.append(("loss", k, abs(got[k] - rv) / abs(rv), rv, 1.0))
+    r, m = rel_err(eng.z_mean.cpu(), ref["z_mean"])
+    rows.append(("act", "z_mean", r, m, 1.0))
+    r, m = rel_err(eng.z_sigma.cpu(), ref["z_sigma"])
+    rows.append(("act", "z_sigma", r, m, 1.0))
+    for k, v in ref["new_stats"].items():
+        if k.endswith("tracked"):
+            rows.append(("stat", k, float(abs(int(eng.buffers[k]) - int(v))), float(v), 1.0))
+        else:
+            r, m = rel_err(eng.buffers[k].cpu(), v)
+            rows.append(("stat", k, r, m, 1.0))
+    return rows, eng, ref
+
+
+def format_rows(rows):
+    out = []
+    for kind, k, r, m, c in rows:
+        out.append("%-5s %-46s rel_err %.3e  ref_max %.3e  cos %.6f" % (kind, k, r, m, c))
+    return "\n".join(out)

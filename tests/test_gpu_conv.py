@@ -1,0 +1,159 @@
+"""Implicit-GEMM kernels (cvg_conv_fwd / cvg_conv_wgrad / cvg_weight_pack) against
+torch's CPU convolution on the same seeded inputs, through the C ABI.
+Tolerances: f32 mode uses exact-f32 MFMA, so only summation order differs from the
+CPU (<= 2e-5 of the tensor's max); bf16 mode rounds inputs to 8 significant bits
+(<= 2e-2 of the tensor's max for these reduction lengths)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def _mods():
+    from cvae_gan_amd import ops
+    from cvae_gan_amd.engine import _desc, _wmap
+    return ops, _desc, _wmap
+
+
+def to_rows(x, dtype):            # NCHW f32 cpu -> [B*H*W][C] device
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().view(-1, x.shape[1])
+
+
+def from_rows(t, B, H, W, C):
+    return t.float().view(B, H, W, C).permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def relmax(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def pack(ops, wmap, w, desc, dtype):
+    packed = torch.zeros(desc.w_rows * desc.w_ld, dtype=dtype, device="cuda")
+    ops.weight_pack(wmap, w.cuda().contiguous(), packed, desc.w_rows, desc.w_ld)
+    return packed
+
+
+def ws_for(ops, desc):
+    n = max(ops.conv_fwd_workspace(desc), ops.conv_wgrad_workspace(desc), 1024)
+    return torch.zeros(n // 4 + 16, dtype=torch.float32, device="cuda")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,cin,cout,stride", [(3, 12, 16, 24, 1), (3, 12, 16, 32, 1), (2, 16, 64, 64, 1),
+                                                 (1, 8, 128, 256, 1), (3, 12, 16, 40, 2), (3, 12, 8, 16, 2),
+                                                 (2, 16, 64, 128, 2)])
+def test_conv3x3_fwd_dgrad_wgrad(dtype, B, H, cin, cout, stride):
+    ops, _desc, _wmap = _mods()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + cin + stride)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    if dtype == torch.bfloat16:   # compare against the same rounded operands
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, 1)
+    dy = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y.backward(dy)
+    OH = H // stride
+    # forward
+    d = _desc(dtype, B, H, H, cin, OH, OH, cout, 3, 9, stride=stride, off=(-1, -1))
+    wm = _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9)
+    ws = ws_for(ops, d)
+    xr = to_rows(x.detach(), dtype)
+    yr = torch.zeros(B * OH * OH, cout, dtype=dtype, device="cuda")
+    ops.conv_fwd(d, xr, pack(ops, wm, w.detach(), d, dtype), yr, ws=ws)
+    assert relmax(from_rows(yr, B, OH, OH, cout), y.detach()) < TOL[dtype]
+    # weight gradient
+    dyr = to_rows(dy, dtype)
+    gw = torch.full(w.shape, 7.0, device="cuda")
+    ops.conv_wgrad(d, xr, dyr, cout, wm, gw, ws)
+    assert relmax(gw.cpu(), w.grad) < TOL[dtype]
+    # input gradient (its k-extent per tap is cout, which the kernels need to be a power of two)
+    if cout & (cout - 1):
+        return
+    dxr = torch.zeros(B * H * H, cin, dtype=dtype, device="cuda")
+    if stride == 1:
+        dd = _desc(dtype, B, H, H, cout, H, H, cin, 3, 9, off=(-1, -1))
+        dm = _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1)
+        ops.conv_fwd(dd, dyr, pack(ops, dm, w.detach(), dd, dtype), dxr, ws=ws_for(ops, dd))
+    else:
+        for py in (0, 1):
+            for px in (0, 1):
+                khs = [1] if py == 0 else [0, 2]
+                kws = [1] if px == 0 else [0, 2]
+                table = [kh * 3 + kw for kh in khs for kw in kws]
+                dd = _desc(dtype, B, OH, OH, cout, OH, OH, cin, len(kws), len(table), tstep=(-1, -1),
+                           off=(1 if py else 0, 1 if px else 0), o_mul=(2, 2), o_off=(py, px), y_dims=(H, H))
+                dm = _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, len(table), tap_mode=2, table=table)
+                ops.conv_fwd(dd, dyr, pack(ops, dm, w.detach(), dd, dtype), dxr, ws=ws_for(ops, dd))
+    torch.cuda.synchronize()
+    assert relmax(from_rows(dxr, B, H, H, cin), x.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_bias_residual_gate(dtype):
+    """Epilogue: bias, per-class bias, residual scaled by the LeakyReLU derivative."""
+    ops, _desc, _wmap = _mods()
+    g = torch.Generator().manual_seed(5)
+    B, H, cin, cout = 5, 8, 32, 48
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 17
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(7, cout, generator=g)
+    labels = torch.randint(0, 7, (B,), generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    gate = torch.randn(B, cout, H, H, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, res, gate = [t.bfloat16().float() for t in (x, w, res, gate)]
+    ref = F.conv2d(x, w, bias, 1, 1) + cb[labels][:, :, None, None] + res * torch.where(gate > 0, 1.0, 0.2)
+    d = _desc(dtype, B, H, H, cin, H, H, cout, 3, 9, off=(-1, -1))
+    wm = _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9)
+    yr = torch.zeros(B * H * H, cout, dtype=dtype, device="cuda")
+    ops.conv_fwd(d, to_rows(x, dtype), pack(ops, wm, w, d, dtype), yr, bias=bias.cuda(), cbias=cb.cuda(),
+                 labels=labels.int().cuda(), res=to_rows(res, dtype), gate=to_rows(gate, dtype), ws=ws_for(ops, d))
+    assert relmax(from_rows(yr, B, H, H, cout), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reflect_7x7_to3(dtype):
+    """Decoder tail: ReflectionPad2d(3) + Conv2d(C, 3, 7) with 3 of 4 stored channels valid."""
+    ops, _desc, _wmap = _mods()
+    from cvae_gan_amd._lib import PAD_REFLECT
+    g = torch.Generator().manual_seed(9)
+    B, P, C = 2, 16, 16
+    x = torch.randn(B, C, P, P, generator=g)
+    w = torch.randn(3, C, 7, 7, generator=g) / 28
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w)
+    d = _desc(dtype, B, P, P, C, P, P, 4, 7, 49, off=(-3, -3), pad_mode=PAD_REFLECT)
+    wm = _wmap(1, C * 49, 0, C, 1, 49, 3, C, 49)
+    yr = torch.zeros(B * P * P, 4, dtype=dtype, device="cuda")
+    ops.conv_fwd(d, to_rows(x, dtype), pack(ops, wm, w, d, dtype), yr, ws=ws_for(ops, d))
+    out = yr.float().view(B, P, P, 4)
+    assert float(out[..., 3].abs().max()) == 0.0
+    assert relmax(out[..., :3].permute(0, 3, 1, 2).cpu(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(6, 1024, 32), (256, 8192, 128), (37, 136, 528)])
+def test_linear_split_k(dtype, M, K, N):
+    """Linear layers run as 1x1 'convolutions'; long K with few tiles takes the split-K path."""
+    ops, _desc, _wmap = _mods()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.linear(x, w, b)
+    d = _desc(dtype, M, 1, 1, K, 1, 1, N, 1, 1)
+    wm = _wmap(1, K, 0, K, 0, 1, N, K, 1)
+    yr = torch.zeros(M, N, dtype=dtype, device="cuda")
+    ops.conv_fwd(d, x.to(dtype).cuda(), pack(ops, wm, w, d, dtype), yr, bias=b.cuda(), ws=ws_for(ops, d))
+    assert relmax(yr.float().cpu(), ref) < TOL[dtype]

@@ -1,0 +1,78 @@
+"""Full train-step parity of the HIP engine (through the C ABI) against the CPU oracle
+on the golden cases.
+
+Tolerances (error relative to the largest magnitude of each reference tensor):
+  f32 mode : activations 1e-4, gradients 1e-3, losses 1e-5.  The arithmetic is exact
+             f32 fma; what remains is summation order amplified by the tiny-batch
+             BatchNorms (the oracle itself differs from the reference by ~1e-4 there).
+  bf16 mode: activations / gradients compared by cosine similarity >= 0.99 and
+             losses within 3e-2, per the bf16 input rounding through 13 stacked convs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, Case
+from parity import run_parity, format_rows
+
+pytestmark = pytest.mark.gpu
+
+ZERO_GRAD = {"encoder.module.conv.1.bias", "encoder.module.fc.0.bias"}   # true gradient is exactly 0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_step_parity_f32(name):
+    rows, eng, ref = run_parity(name, torch.float32)
+    bad = []
+    for kind, k, r, m, c in rows:
+        if k in ZERO_GRAD:
+            continue
+        tol = {"act": 1e-4, "dact": 1e-3, "grad": 1e-3, "loss": 1e-5, "stat": 1e-4}[kind]
+        if not r <= tol:
+            bad.append((kind, k, r, m, c))
+    assert not bad, "\n" + format_rows(bad)
+    # losses also against the fixture recorded from the reference classes
+    c = Case(name)
+    got = eng.read_losses()
+    for k in ("VAE", "KL", "LL"):
+        refv = float(c.npz["s0/" + k])
+        assert abs(got[k] - refv) <= 2e-5 * abs(refv), (k, got[k], refv)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_step_parity_bf16(name):
+    rows, eng, ref = run_parity(name, torch.bfloat16)
+    bad = []
+    for kind, k, r, m, c in rows:
+        if k in ZERO_GRAD:
+            continue
+        if kind == "loss":
+            ok = r <= 3e-2
+        elif kind == "stat":
+            ok = r <= 3e-2
+        else:
+            ok = c >= 0.99
+        if not ok:
+            bad.append((kind, k, r, m, c))
+    assert not bad, "\n" + format_rows(bad)
+
+
+def test_three_steps_f32_match_golden():
+    """Three AdamW steps from the fixture's initial weights: per-step losses against the
+    values recorded from the reference classes."""
+    from collections import OrderedDict
+    from cvae_gan_amd.engine import Engine
+    c = Case("ragged_p32_ngf8")
+    e, d = c.init_state()
+    st = OrderedDict(e)
+    st.update(d)
+    eng = Engine(c.P, c.y, c.z, c.B, dtype=torch.float32, ngf=c.ngf, state=st)
+    for step in range(c.n_steps):
+        x, labels, eps, mask = c.inputs(step)
+        eng.set_mask(mask)
+        eng.train_step(x.cuda(), labels.int().cuda(), eps.cuda(), float(c.bs_flag), c.lr)
+        got = eng.read_losses()
+        for k in ("VAE", "KL", "LL"):
+            refv = float(c.npz["s%d/%s" % (step, k)])
+            tol = 2e-5 if step == 0 else 2e-3     # AdamW's first steps amplify rounding (sign of ~0 gradients)
+            assert abs(got[k] - refv) <= tol * abs(refv), (step, k, got[k], refv)
