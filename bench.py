@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Throughput of the CVAE train step on MI355X (BASELINE.json metric: train images/sec at
+64x64, batch 256 per GPU), with the roofline of the dominant kernel and a CPU baseline.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward + KL/MSE losses + backward + gradient all-reduce (N > 1) + AdamW over one
+synthetic batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (pix_dim, y_dim, z_dim, per-GPU batch)   -- z_dim 32 from the reference's train.sh:6
+    "c2": (32, 10, 32, 256),
+    "c3": (64, 100, 32, 256),
+    "c4": (128, 100, 32, 64),
+}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+
+def make_batches(eng, n, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    out = []
+    for _ in range(n):
+        x = torch.rand(eng.B, 3, eng.P, eng.P, device="cuda", generator=g) * 2 - 1
+        labels = torch.randint(0, eng.y, (eng.B,), device="cuda", generator=g, dtype=torch.int32)
+        eps = torch.randn(eng.B, eng.z, device="cuda", generator=g)
+        out.append((x, labels, eps))
+    return out
+
+
+def gemm_flops(g):
+    """Algorithmic FLOPs of one launch of a packed GEMM (forward, dgrad or wgrad): 2*M*N*K over
+    the layer's real channels and taps (the zero padding the kernels add is not counted)."""
+    d, m = g.desc, g.wmap
+    M = d.B * d.OH * d.OW
+    n = m.n_valid
+    k = m.kc_valid * (sum(1 for i in range(m.ntaps) if m.tap_table[i] >= 0) if m.tap_mode == 2 else m.ntaps)
+    return 2.0 * M * n * k
+
+
+class KernelTimer:
+    """HIP-event brackets around every implicit-GEMM launch, on the stream they are launched on."""
+
+    def __init__(self, eng):
+        self.eng, self.records = eng, []
+        self._fwd, self._wgrad = eng._fwd, eng._wgrad
+
+    def __enter__(self):
+        eng = self.eng
+
+        def fwd(g, x, y, bias=None, **kw):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._fwd(g, x, y, bias=bias, **kw)
+            b.record()
+            self.records.append((self.kernel_name(g, "fwd"), gemm_flops(g), a, b))
+
+        def wgrad(g, x, dy, dy_ld):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._wgrad(g, x, dy, dy_ld)
+            b.record()
+            self.records.append((self.kernel_name(g, "wgrad"), gemm_flops(g), a, b))
+
+        eng._fwd, eng._wgrad = fwd, wgrad
+        return self
+
+    def __exit__(self, *exc):
+        self.eng._fwd, self.eng._wgrad = self._fwd, self._wgrad
+
+    @staticmethod
+    def kernel_name(g, kind):
+        n = g.desc.N
+        if kind == "fwd":
+            tile = "128x128" if n > 64 else ("256x64" if n > 32 else "256x32")
+            return "igemm_fwd<%s>" % tile
+        tile = "128x128" if n > 64 else ("64x128" if n > 32 else "32x128")
+        return "igemm_wgrad<%s>(+reduce)" % tile
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, a, b in self.records:
+            t = a.elapsed_time(b) * 1e-3
+            s = agg.setdefault(name, [0.0, 0.0, 0])
+            s[0] += fl
+            s[1] += t
+            s[2] += 1
+        return agg
+
+
+def cpu_baseline(P, y, z, seconds_budget=20.0):
+    """The CPU oracle (a port of the reference's step, pinned to the reference by the golden
+    fixtures) timed on this host: fp32, B=32, same synthetic distribution."""
+    from oracle import ref_cpu as O
+    B = 32
+    e, d = O.init_params(P, y, z, seed=0)
+    st = O.TrainState(e, d)
+    g = torch.Generator().manual_seed(0)
+    F = 4 * (z + y)
+
+    def one():
+        x = torch.rand(B, 3, P, P, generator=g) * 2 - 1
+        labels = torch.randint(0, y, (B,), generator=g)
+        eps = torch.randn(B, z, generator=g)
+        mask = (torch.rand(B, F, generator=g) < 0.5).float()
+        O.train_step(st, x, labels, eps, mask, y, B, 3e-5)
+
+    one()                                   # warm-up
+    t0, n = time.time(), 0
+    while n < 3 or (time.time() - t0 < seconds_budget and n < 10):
+        one()
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "%d steps of the fp32 CPU oracle at %dx%d, %d classes, batch %d" % (n, P, P, y, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--lr", type=float, default=3e-5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    from cvae_gan_amd.engine import Engine
+    from cvae_gan_amd import ddp
+
+    P, y, z, B = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    eng = Engine(P, y, z, B, dtype=dtype, seed=0)
+    ddp.broadcast_state(eng)
+    sync = None
+    if world > 1:
+        sync = ddp.GradSync(eng.g_arena, ddp.stage_ranges(eng.arena_order, eng.arena_offsets, eng.arena_numel),
+                            ddp.STAGES)
+        eng.grad_ready = sync.on_ready
+    batches = make_batches(eng, 4, 1234 + rank)
+    batch_size_flag = float(B * world)       # the reference divides both losses by --batch_size (global)
+    loss_scale = 1.0 / world
+
+    def step(i):
+        x, labels, eps = batches[i % len(batches)]
+        eng.random_mask()
+        if sync:
+            sync.begin_step()
+        eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
+        if sync:
+            sync.finish()
+        eng.adamw_step(args.lr)
+
+    # A HIP graph of one whole step removes the per-launch host cost (about 400 launches per step).
+    # With the all-reduce in the step (N > 1) the step is launched eagerly.
+    use_graph = (world == 1) and not args.no_graph
+    graph = None
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    torch.cuda.synchronize()
+    if use_graph:
+        x0, l0, e0 = batches[0]
+        gx, gl, ge = x0.clone(), l0.clone(), e0.clone()
+        graph = torch.cuda.CUDAGraph()
+        eng.pack_weights(force=True)
+        saved = eng.step_count
+        with torch.cuda.graph(graph):
+            eng.random_mask()
+            eng._packed_version = -1
+            eng.forward_backward(gx, gl, ge, batch_size_flag, loss_scale)
+            eng.adamw_step(args.lr)
+        eng.step_count = saved
+
+        def step(i):                                    # noqa: F811
+            x, labels, eps = batches[i % len(batches)]
+            gx.copy_(x)
+            gl.copy_(labels)
+            ge.copy_(eps)
+            graph.replay()
+
+        step(0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = eng.read_losses()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: event-bracketed launches of two more (eager) steps
+    eng.grad_ready = None
+    with KernelTimer(eng) as kt:
+        for i in range(2):
+            x, labels, eps = batches[i % len(batches)]
+            eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
+        agg = kt.summary()
+    name, (fl, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    achieved = fl / t / 1e12
+    total_gemm_t = sum(v[1] for v in agg.values()) / 2
+    roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
+                "all_gemm_ms_per_step": round(total_gemm_t * 1e3, 3),
+                "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3)}
+                               for k, v in sorted(agg.items())}}
+
+    out = {
+        "metric": "train images/sec", "value": round(B * world * args.steps / dt, 1), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "CVAE train step (encoder+sampler+decoder fwd/bwd, KL+MSE, AdamW), %dx%dx3, %d classes, "
+                               "z_dim %d, per-GPU batch %d, random-init weights" % (P, P, y, z, B),
+                   "name": args.config, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "launch": "hip-graph" if use_graph else "eager"},
+        "losses_last_step": {k: round(v, 6) for k, v in losses.items()},
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(P, y, z)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

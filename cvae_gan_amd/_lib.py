@@ -69,6 +69,8 @@ def _load():
         "cvg_tanh_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "cvg_mse_fwd_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, vp, vp]),
         "cvg_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+        "cvg_adamw_dev": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
+        "cvg_dropout_mask_dev": (C.c_int, [vp, i64, vp, vp]),
         "cvg_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
         "cvg_nhwc_to_nchw": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
         "cvg_nchw_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),

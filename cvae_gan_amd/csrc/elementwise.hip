@@ -570,6 +570,46 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// Device-resident step counter: the bias corrections are recomputed on the device so that a
+// captured HIP graph of the step advances AdamW exactly like eager launches do.
+__global__ void adamw_tick(long long* step, float* bc, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long t = *step + 1;
+        *step = t;
+        bc[0] = (float)(1.0 / (1.0 - pow((double)b1, (double)t)));
+        bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+    }
+}
+__global__ void adamw_kernel_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                 const float* __restrict__ bc) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float inv_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
+    const int cnt = n - i < 4 ? (int)(n - i) : 4;
+    for (int j = 0; j < cnt; ++j) {
+        const int64_t k = i + j;
+        float pp = p[k] * (1.f - lr * wd);
+        const float gg = g[k];
+        const float mm = b1 * m[k] + (1.f - b1) * gg;
+        const float vv = b2 * v[k] + (1.f - b2) * gg * gg;
+        pp -= lr * inv_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        p[k] = pp; m[k] = mm; v[k] = vv;
+    }
+}
+__global__ void dropout_mask_dev(uint8_t* mask, int64_t n, const long long* seed_ctr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t v = (uint64_t)i + (uint64_t)(*seed_ctr) * 0x9E3779B97F4A7C15ull;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    v ^= v >> 31;
+    mask[i] = (uint8_t)((v >> 40) & 1u);
+}
+__global__ void counter_tick(long long* c) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
+}
+
 // ---- launch helpers ------------------------------------------------------------------------------------
 int red_threads(int C) { const int CC = C / 8; return CC * (256 / CC); }
 int red_blocks(int M, int C) {
@@ -795,6 +835,26 @@ int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     adamw_kernel<<<grid1(ceil_div(n, 4)), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                                                                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t* step_counter, float* bc, cvg_stream stream) {
+    CVG_CHECK(p && g && m && v && n > 0 && step_counter && bc, "adamw_dev: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    adamw_tick<<<1, 64, 0, s>>>((long long*)step_counter, bc, beta1, beta2);
+    CVG_LAUNCH_CHECK();
+    adamw_kernel_dev<<<grid1(ceil_div(n, 4)), 256, 0, s>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_dropout_mask_dev(uint8_t* mask, int64_t n, int64_t* seed_counter, cvg_stream stream) {
+    CVG_CHECK(mask && n > 0 && seed_counter, "dropout_mask_dev: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    counter_tick<<<1, 64, 0, s>>>((long long*)seed_counter);
+    CVG_LAUNCH_CHECK();
+    dropout_mask_dev<<<grid1(n), 256, 0, s>>>(mask, n, (const long long*)seed_counter);
     CVG_LAUNCH_CHECK();
     return 0;
 }

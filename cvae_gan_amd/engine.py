@@ -195,6 +195,7 @@ class Engine:
         self._gemms, self._ws_bytes = [], 0
         self.step_count = 0
         self.training = True
+        self.grad_ready = None      # callable(stage) -> None, see cvae_gan_amd/ddp.py
         self._build_params(seed, state)
         self._build_encoder()
         self._build_decoder()
@@ -430,6 +431,9 @@ class Engine:
         self.eps = self._f(B, self.z)
         self.z_mean, self.z_sigma = self._f(B, self.z), self._f(B, self.z)
         self.losses = self._f(4)          # [kl, ll, -, -]
+        self.step_dev = torch.zeros(1, dtype=torch.long, device=self.device)     # AdamW step count
+        self.seed_dev = torch.zeros(1, dtype=torch.long, device=self.device)     # dropout stream position
+        self.bc_dev = self._f(2)
 
     def _build_workspaces(self):
         wg = 0
@@ -464,6 +468,10 @@ class Engine:
     def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix):
         ops.bn_act_bwd(dy, y, x, dx, M, C, stats, self.params[prefix + ".weight"],
                        self.grads[prefix + ".weight"], self.grads[prefix + ".bias"], self.red_ws)
+
+    def _ready(self, stage):
+        if self.grad_ready is not None:
+            self.grad_ready(stage)
 
     def _fwd(self, g, x, y, bias=None, **kw):
         ops.conv_fwd(g.desc, x, g.w, y, bias=bias, ws=self.ws, **kw)
@@ -506,6 +514,7 @@ class Engine:
         self._wgrad(e["fc0"], last["out"], e["d_f0"], e["fcd"])
         ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws)
         self._fwd(e["fc0_dg"], e["d_f0"], last["d_out"])
+        self._ready("enc.head")
         for i in range(len(e["blocks"]) - 1, -1, -1):
             blk = e["blocks"][i]
             p, M, C = blk["prefix"], blk["M"], blk["cin"]
@@ -520,10 +529,12 @@ class Engine:
             d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
             # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
             self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
+            self._ready("enc.blk%d" % i)
         self._bn_bwd(e["d_a0"], e["a0"], e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
         self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
         ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
                            self.grads[EP + "conv.1.bias"], self.red_ws)
+        self._ready("enc.stem")
 
     # ------------------------------------------------------------------ sampler
     def sample(self, h, eps, batch_size):
@@ -590,6 +601,7 @@ class Engine:
         ops.colsum(d["d_g0"], B, d["F8"], d["F8"], d["bgradF8"], self.red_ws)
         ops.permute_f32(d["bgradF8"], self.grads[DP + "fc.0.bias"], d["F"])
         self._fwd(d["fc0_dg"], d["d_g0"], d["dzin"])
+        self._ready("dec")
         return d["dzin"]
 
     # ------------------------------------------------------------------ fused step
@@ -599,9 +611,14 @@ class Engine:
         d["mask"].zero_()
         d["mask"][:, :d["F"]] = keep.to(self.device).to(torch.uint8)
 
-    def random_mask(self, seed):
+    def random_mask(self, seed=None):
+        """Fresh Bernoulli(0.5) keep mask.  seed=None draws from the device-side counter
+        (advances on every call, also under HIP-graph replay)."""
         d = self.dec
-        ops.dropout_mask(d["mask"], d["mask"].numel(), seed)
+        if seed is None:
+            ops.dropout_mask_dev(d["mask"], d["mask"].numel(), self.seed_dev)
+        else:
+            ops.dropout_mask(d["mask"], d["mask"].numel(), seed)
 
     def forward_backward(self, x, labels, eps, batch_size, loss_scale=1.0):
         """Forward + loss + backward of models/cvae.py:132-152 with every reduction on
@@ -620,8 +637,8 @@ class Engine:
 
     def adamw_step(self, lr, betas=ADAM_BETAS, eps=ADAM_EPS, weight_decay=ADAM_WD):
         self.step_count += 1
-        ops.adamw(self.p_arena, self.g_arena, self.m_arena, self.v_arena, self.arena_numel, lr, betas[0],
-                  betas[1], eps, weight_decay, self.step_count)
+        ops.adamw_dev(self.p_arena, self.g_arena, self.m_arena, self.v_arena, self.arena_numel, lr, betas[0],
+                      betas[1], eps, weight_decay, self.step_dev, self.bc_dev)
         self._param_version += 1
 
     def train_step(self, x, labels, eps, batch_size, lr):

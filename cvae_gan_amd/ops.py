@@ -148,6 +148,15 @@ def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step):
     check(lib.cvg_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, wd, step, stream()))
 
 
+def adamw_dev(p, g, m, v, n, lr, beta1, beta2, eps, wd, step_counter, bc):
+    check(lib.cvg_adamw_dev(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, wd, ptr(step_counter),
+                            ptr(bc), stream()))
+
+
+def dropout_mask_dev(mask, n, seed_counter):
+    check(lib.cvg_dropout_mask_dev(ptr(mask), n, ptr(seed_counter), stream()))
+
+
 def cast(src, out, n):
     check(lib.cvg_cast(ptr(src), dt(src), ptr(out), dt(out), n, stream()))
 

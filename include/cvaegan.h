@@ -210,6 +210,15 @@ int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, i
 int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, int32_t step, cvg_stream s);
 
+/* The same with the step count kept on the device: *step_counter (int64) is incremented
+ * and the bias corrections are written to bc[2] by a one-thread kernel before the update,
+ * so a captured HIP graph of the step replays a correct optimiser.                    */
+int cvg_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t* step_counter, float* bc,
+                  cvg_stream s);
+/* Keep mask seeded by a device counter that advances on every call (graph-replay safe). */
+int cvg_dropout_mask_dev(uint8_t* mask, int64_t n, int64_t* seed_counter, cvg_stream s);
+
 /* f32 <-> dtype copies of dense buffers (module-boundary conversions).             */
 int cvg_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n,
              cvg_stream s);
