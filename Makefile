@@ -3,13 +3,13 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 SRC_DIR := cvae_gan_amd/csrc
 LIB     := cvae_gan_amd/lib/libcvaegan_hip.so
-SRCS    := $(SRC_DIR)/api.hip $(SRC_DIR)/igemm.hip $(SRC_DIR)/elementwise.hip
+SRCS    := $(SRC_DIR)/api.hip $(SRC_DIR)/igemm.hip $(SRC_DIR)/conv_patch.hip $(SRC_DIR)/elementwise.hip
 OBJS    := $(SRCS:.hip=.o)
 FLAGS   := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude
 
 all: $(LIB)
 
-$(SRC_DIR)/%.o: $(SRC_DIR)/%.hip $(SRC_DIR)/common.h include/cvaegan.h
+$(SRC_DIR)/%.o: $(SRC_DIR)/%.hip $(SRC_DIR)/common.h $(SRC_DIR)/gemm_util.h $(SRC_DIR)/conv_patch.h include/cvaegan.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

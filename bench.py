@@ -65,14 +65,14 @@ class KernelTimer:
             a.record()
             self._fwd(g, x, y, bias=bias, **kw)
             b.record()
-            self.records.append((self.kernel_name(g, "fwd"), gemm_flops(g), a, b))
+            self.records.append((self.kernel_name(g, "fwd"), gemm_flops(g), a, b, g))
 
         def wgrad(g, x, dy, dy_ld):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             self._wgrad(g, x, dy, dy_ld)
             b.record()
-            self.records.append((self.kernel_name(g, "wgrad"), gemm_flops(g), a, b))
+            self.records.append((self.kernel_name(g, "wgrad"), gemm_flops(g), a, b, g))
 
         eng._fwd, eng._wgrad = fwd, wgrad
         return self
@@ -89,10 +89,26 @@ class KernelTimer:
         tile = "128x128" if n > 64 else ("64x128" if n > 32 else "32x128")
         return "igemm_wgrad<%s>(+reduce)" % tile
 
+    def per_layer(self, reps):
+        """One line per GEMM launch site: layer, kind, GEMM shape, time, algorithmic TFLOP/s."""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, a, b, g in self.records:
+            d = g.desc
+            key = (g.key.replace("encoder.module.", "E.").replace("decoder.module.", "D."), name,
+                   d.B * d.OH * d.OW, d.N, d.ntaps * d.Cin, d.stride, d.oy_off * 2 + d.ox_off)
+            s = agg.setdefault(key, [fl, 0.0])
+            s[1] += a.elapsed_time(b) * 1e-3 / reps
+        lines = []
+        for (key, name, M, N, K, st, cls), (fl, t) in agg.items():
+            lines.append("%-28s %-30s M %8d N %5d K %5d s%d c%d  %8.1f us  %7.1f TF" % (
+                key, name, M, N, K, st, cls, t * 1e6, fl / t / 1e12))
+        return "\n".join(lines)
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, a, b in self.records:
+        for name, fl, a, b, _ in self.records:
             t = a.elapsed_time(b) * 1e-3
             s = agg.setdefault(name, [0.0, 0.0, 0])
             s[0] += fl
@@ -139,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--lr", type=float, default=3e-5)
+    ap.add_argument("--per-layer", action="store_true", help="print a per-layer GEMM table to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -235,6 +252,8 @@ def main():
             x, labels, eps = batches[i % len(batches)]
             eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
         agg = kt.summary()
+        if args.per_layer:
+            print(kt.per_layer(2), file=sys.stderr)
     name, (fl, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     achieved = fl / t / 1e12

@@ -46,7 +46,7 @@ def _load():
         "cvg_conv_fwd": (C.c_int, [P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "cvg_conv_wgrad_workspace": (sz, [P(ConvDesc)]),
         "cvg_conv_wgrad": (C.c_int, [P(ConvDesc), vp, vp, i32, P(WMap), vp, i32, vp, sz, vp]),
-        "cvg_weight_pack": (C.c_int, [P(WMap), vp, vp, i32, i32, i32, vp]),
+        "cvg_weight_pack": (C.c_int, [P(ConvDesc), P(WMap), vp, vp, vp]),
         "cvg_label_bias": (C.c_int, [vp, vp, i32, i32, vp]),
         "cvg_label_bias_bwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "cvg_pack_image": (C.c_int, [vp, vp, i32, i32, i32, vp]),

@@ -1,0 +1,38 @@
+// Patch-staged convolution kernels: the input tile plus its halo is staged ONCE per
+// 32-channel chunk in LDS and every tap reads its MFMA operand from the shifted patch,
+// instead of re-gathering the im2col rows from L2 for every tap.
+#pragma once
+#include "common.h"
+
+struct PatchPlan {
+    int ok;
+    int BM, BN;                  // pixels x output channels per workgroup
+    int TB, TH, TW;              // tile: images x rows x cols (TB*TH*TW <= BM)
+    int PH, PW;                  // patch rows/cols per image = TH+KH-1, TW+KW-1
+    int KH, KW, T;
+    int tiles_y, tiles_x, groups;
+    int patch_px, nchunks;
+    size_t lds_bytes;
+};
+
+// Forward / input-gradient.  plan.ok == 0: not eligible (the gather kernel handles it).
+void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p);
+int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
+                     const float* bias, const float* cbias, const int32_t* labels, const void* res,
+                     const void* gate, hipStream_t s);
+// Weights in MFMA-fragment order: [n/32][chunk][tap][k16 half][lane][8].
+int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap* map, const float* canonical,
+                      void* packed, hipStream_t s);
+
+// Weight gradient.
+struct PatchWgradPlan {
+    int ok;
+    int BNW, WN, WT;             // output channels per workgroup, waves over n, waves over taps
+    int TB, TH, TW, PH, PW, KH, KW, T;
+    int tiles_y, tiles_x, groups, ntiles, nsplit, tiles_per_split;
+    int patch_px, nchunks, n_tiles;
+    size_t lds_bytes, ws_bytes;
+};
+void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p);
+int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const void* x, const void* dy, int dy_ld,
+                       const cvg_wmap* map, float* grad, int accumulate, float* ws, hipStream_t s);

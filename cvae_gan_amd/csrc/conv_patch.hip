@@ -1,0 +1,672 @@
+// Patch-staged convolution kernels for gfx950 (stride-1 convolutions with >= 32 channels).
+//
+// A workgroup owns TB x TH x TW output pixels.  Per 32-channel chunk it stages the
+// (TH+KH-1) x (TW+KW-1) input patch of each of its images in LDS once; every tap then
+// reads its MFMA operand from the patch at a shifted pixel, so each input element
+// comes from L2 about 1.3 times instead of KH*KW times.
+//
+//   patch_fwd    Y[pix][n]  = sum_{tap,c} X[pix+tap][c] * W[n][tap][c]
+//                weights arrive pre-packed in MFMA-fragment order and stream straight
+//                from L2 into registers (1 KiB coalesced per wave-instruction, no LDS)
+//   patch_wgrad  P[n][tap][c] = sum_pix dY[pix][n] * X[pix+tap][c]
+//                both operands are read from LDS with transposing reads; the dY
+//                fragment is reused across all taps
+#include "conv_patch.h"
+#include "gemm_util.h"
+
+namespace {
+
+constexpr int CK = 32;            // channels per staged chunk
+
+struct TileGeom {
+    int TB, TH, TW, PH, PW, npx;           // npx = TB*TH*TW valid tile pixels
+    int tiles_x;
+    FastDiv div_tw, div_thw, div_pw, div_phw, div_tx;
+};
+
+struct PatchFwdArgs {
+    const void* x; const void* wf; void* y;
+    const float* bias; const float* cbias; const int* labels; const void* res; const void* gate;
+    int B, H, W, Cin, x_img_pitch, x_row_pitch;
+    int off_y, off_x, pad_mode, KW, T;
+    int OH, OW, N;
+    int y_img_pitch, y_row_pitch, y_pix_pitch, oy_mul, oy_off, ox_mul, ox_off;
+    int nchunks, patch_px, patch_bytes;
+    TileGeom t;
+};
+
+__device__ __forceinline__ bool pad_xy(int pad_mode, int H, int W, int& iy, int& ix) {
+    if (pad_mode == CVG_PAD_REFLECT) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= H ? 2 * H - 2 - iy : iy;
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= W ? 2 * W - 2 - ix : ix;
+        return true;
+    }
+    return (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+}
+
+// tile pixel q -> (tb, ty, tx)
+__device__ __forceinline__ void tile_px(const TileGeom& t, int q, int& tb, int& ty, int& tx) {
+    tb = fdiv(q, t.div_thw);
+    const int r = q - tb * (t.TH * t.TW);
+    ty = fdiv(r, t.div_tw);
+    tx = r - ty * t.TW;
+}
+
+// ======================================================================================
+// forward
+// ======================================================================================
+template <typename T, int WM, int WN, int MI, int NI>
+__global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CPP = CK * ES / 16;            // 16-byte pieces per patch pixel
+    constexpr int PITCH = CK * ES + 16;          // conflict-free ds_read_b128 across pixels
+    constexpr int NIT = 2 * CPP;                 // patch pieces per thread (patch_px <= 512)
+    constexpr int WTM = MI * 32, WTN = NI * 32, BN = WN * WTN;
+    constexpr int FRAG = 64 * 8;                 // elements per packed fragment (one wave-load)
+    constexpr int D = 4;                         // weight steps in flight per wave
+    typedef typename Elem<T>::frag frag;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const TileGeom& t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tile_y = fdiv(blockIdx.x, t.div_tx), tile_x = blockIdx.x - tile_y * t.tiles_x;
+    const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = blockIdx.z * t.TB, n0 = blockIdx.y * BN;
+    const T* __restrict__ xp = (const T*)a.x;
+
+    // ---- patch pieces of this thread: global element offset (chunk 0) or -1 for zero fill
+    int gofs[NIT];
+    const int nitems = a.patch_px * CPP;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + 256 * i;
+        gofs[i] = -1;
+        if (idx < nitems) {
+            const int p = idx / CPP, ci = idx % CPP;
+            const int tb = fdiv(p, t.div_phw);
+            const int r = p - tb * (t.PH * t.PW);
+            const int py = fdiv(r, t.div_pw), px = r - py * t.PW;
+            int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
+            const int b = b0 + tb;
+            if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix))
+                gofs[i] = b * a.x_img_pitch + iy * a.x_row_pitch + ix * a.Cin + ci * (16 / ES);
+        }
+    }
+    u32x4 pv[NIT];
+    auto load_patch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (gofs[i] >= 0) v = *(const u32x4*)(xp + (size_t)gofs[i] + chunk * CK);
+            pv[i] = v;
+        }
+    };
+    auto store_patch = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nitems) *(u32x4*)(buf + (idx / CPP) * PITCH + (idx % CPP) * 16) = pv[i];
+        }
+    };
+
+    // ---- this lane's pixel columns
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        int q = wm * WTM + mi * 32 + l31;
+        if (q >= t.npx) q = 0;
+        int tb, ty, tx;
+        tile_px(t, q, tb, ty, tx);
+        abase[mi] = ((tb * t.PH + ty) * t.PW + tx) * PITCH + 8 * h * ES;
+    }
+
+    // ---- weight fragment streams (one per 32-row block of this wave), D steps in flight:
+    // the fragments of step s+D are requested as soon as step s has consumed its own, so
+    // an L2 round trip is covered by D steps of MFMA work.
+    const int nsteps = a.nchunks * a.T;          // (chunk, tap) steps; two k16 fragments each
+    const T* wptr[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        wptr[ni] = (const T*)a.wf + ((size_t)((n0 + wn * WTN) / 32 + ni) * nsteps * 2) * FRAG + lane * 8;
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    frag wr[D][NI][2];
+    auto load_w = [&](int step, frag (&w)[NI][2]) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            w[ni][0] = *(const frag*)(wptr[ni] + (size_t)(step * 2) * FRAG);
+            w[ni][1] = *(const frag*)(wptr[ni] + (size_t)(step * 2 + 1) * FRAG);
+        }
+    };
+
+    load_patch(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nsteps) load_w(d, wr[d]);
+    store_patch(smem);
+    __syncthreads();
+    if (a.nchunks > 1) load_patch(1);
+
+    int chunk = 0, kh = 0, kw = 0, tap = 0;
+    const char* buf = smem;
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int s = s0 + d;
+            if (s < nsteps) {
+                const int tapoff = (kh * t.PW + kw) * PITCH;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    frag xf[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        xf[mi] = *(const frag*)(buf + abase[mi] + tapoff + sub * 16 * ES);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[d][ni][sub], xf[mi]);
+                }
+                if (s + D < nsteps) load_w(s + D, wr[d]);
+                if (++kw == a.KW) { kw = 0; ++kh; }
+                if (++tap == a.T) {
+                    // chunk boundary: publish the next patch, fetch the one after it
+                    tap = kh = kw = 0;
+                    ++chunk;
+                    if (chunk < a.nchunks) {
+                        char* nb = smem + (chunk & 1) * a.patch_bytes;
+                        store_patch(nb);
+                        __syncthreads();
+                        buf = nb;
+                        if (chunk + 1 < a.nchunks) load_patch(chunk + 1);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: D[row = n][col = pixel]
+    T* __restrict__ yp = (T*)a.y;
+    const T* __restrict__ resp = (const T*)a.res;
+    const T* __restrict__ gatep = (const T*)a.gate;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int q = wm * WTM + mi * 32 + l31;
+        if (q >= t.npx) continue;
+        int tb, ty, tx;
+        tile_px(t, q, tb, ty, tx);
+        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+        if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
+        const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
+                            (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+        const float* cb = a.cbias ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wn * WTN + ni * 32 + 8 * g4 + 4 * h;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g4 + j];
+                if (a.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
+                }
+                if (cb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
+                }
+                if (resp) {
+                    float r[4];
+                    load4<T>(resp + yoff + n, r);
+                    if (gatep) {
+                        float gt[4];
+                        load4<T>(gatep + yoff + n, gt);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += r[j];
+                }
+                store4<T>(yp + yoff + n, v);
+            }
+        }
+    }
+}
+
+// weights -> fragment order: element ((nblk * nk2*2 + kstep) * 64 + lane) * 8 + j holds
+// W[n = nblk*32 + (lane & 31)][tap][c = chunk*32 + (kstep & 1)*16 + 8*(lane >> 5) + j]
+template <typename T>
+__global__ void patch_pack(const float* __restrict__ canonical, T* __restrict__ packed, const cvg_wmap map, int rows,
+                           int nchunks, int ntaps, int Cin) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nk = nchunks * ntaps * 2;
+    if (idx >= (int64_t)rows * nk * 16) return;      // rows/32 * nk * 64 * 8 elements
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const int64_t f = idx >> 9;
+    const int kstep = (int)(f % nk), nblk = (int)(f / nk);
+    const int n = nblk * 32 + (lane & 31);
+    const int chunk = kstep / (2 * ntaps), tap = (kstep >> 1) % ntaps, sub = kstep & 1;
+    const int c = chunk * CK + sub * 16 + 8 * (lane >> 5) + j;
+    const int ci = wmap_index(map, n, tap * Cin + c);
+    packed[idx] = from_f32<T>(ci >= 0 ? canonical[ci] : 0.f);
+}
+
+// ======================================================================================
+// weight gradient
+// ======================================================================================
+struct PatchWgradArgs {
+    const void* x; const void* dy; float* ws;
+    int B, H, W, Cin, x_img_pitch, x_row_pitch;
+    int off_y, off_x, pad_mode, KW, T;
+    int OH, OW, dy_ld, dy_cols;
+    int patch_px, ntiles, tiles_per_split, tiles_per_group;
+    int n_rows, k_ld;
+    TileGeom t;
+    FastDiv div_tpg;
+};
+
+// Transposed operand fetch with per-pixel addresses: slot (h, j) of the fragment is tile
+// pixel q0 + 8h + j (bf16) or q0 + 2j + h (f32), whose LDS row address comes from `addr`.
+template <typename T> struct TrGather;
+template <> struct TrGather<bf16> {
+    static constexpr int NADDR = 2;
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    template <typename F>
+    __device__ static __forceinline__ bf16x8 ld(F addr, int q0, int c0, int lane) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, blk = (lane >> 4) & 1, h = lane >> 5;
+        const int cofs = (c0 + 16 * blk + 4 * p) * 2;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(addr(q0 + 8 * h + q) + cofs));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(addr(q0 + 8 * h + q + 4) + cofs));
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+        return r;
+    }
+    // channel block 0..31: row addresses (with this lane's channel offset folded in)
+    template <typename F>
+    __device__ static __forceinline__ void rows(F addr, int q0, int lane, const char* (&out)[2]) {
+        const int i = lane & 15, q = i >> 2, p = i & 3, blk = (lane >> 4) & 1, h = lane >> 5;
+        const int cofs = (16 * blk + 4 * p) * 2;
+        out[0] = addr(q0 + 8 * h + q) + cofs;
+        out[1] = addr(q0 + 8 * h + q + 4) + cofs;
+    }
+    __device__ static __forceinline__ bf16x8 ld_rows(const char* const (&rows_)[2], int off, int lane) {
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(rows_[0] + off));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(rows_[1] + off));
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+        return r;
+    }
+};
+template <> struct TrGather<float> {
+    static constexpr int NADDR = 8;
+    template <typename F>
+    __device__ static __forceinline__ f32x8 ld(F addr, int q0, int c0, int lane) {
+        const int l31 = lane & 31, h = lane >> 5;
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = *(const float*)(addr(q0 + 2 * j + h) + (c0 + l31) * 4);
+        return r;
+    }
+    template <typename F>
+    __device__ static __forceinline__ void rows(F addr, int q0, int lane, const char* (&out)[8]) {
+        const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = addr(q0 + 2 * j + h) + l31 * 4;
+    }
+    __device__ static __forceinline__ f32x8 ld_rows(const char* const (&rows_)[8], int off, int lane) {
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = *(const float*)(rows_[j] + off);
+        return r;
+    }
+};
+
+template <typename T, int WN, int WT, int TPW>
+__global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BNW = 32 * WN;
+    constexpr int BMP = ES == 2 ? 256 : 128;                  // tile pixels
+    constexpr int CPP = CK * ES / 16;
+    constexpr int PP = CK * ES;                                // patch pixel pitch: 64 B rows are conflict-free for tr reads
+    constexpr int GW = BNW * ES;                               // dY row bytes
+    constexpr int PG = (GW == 64 || ES == 4) ? GW : GW + 64;
+    constexpr int NIT = 8;                                     // patch pieces per thread (512 / 256 px)
+    constexpr int GPR = GW / 16;                               // dY pieces per row
+    constexpr int GIT = BMP * GPR / 256;                       // dY pieces per thread
+    typedef typename Elem<T>::frag frag;
+    static_assert(WN * WT == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const TileGeom& t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WT, wt = wave % WT;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int chunk = blockIdx.x, n0 = blockIdx.y * BNW;
+    const T* __restrict__ xp = (const T*)a.x;
+    const T* __restrict__ gp = (const T*)a.dy;
+    char* Ps = smem;
+    char* Gs = smem + ((a.patch_px * PP + 255) & ~255);
+
+    const int tl_beg = blockIdx.z * a.tiles_per_split;
+    const int tl_end = min(a.ntiles, tl_beg + a.tiles_per_split);
+    const int nitems = a.patch_px * CPP;
+
+    u32x4 pv[NIT], gv[GIT];
+    auto load_tile = [&](int tl) {
+        const int grp = fdiv(tl, a.div_tpg);
+        const int r = tl - grp * a.tiles_per_group;
+        const int tile_y = fdiv(r, t.div_tx), tile_x = r - tile_y * t.tiles_x;
+        const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = grp * t.TB;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < nitems) {
+                const int p = idx / CPP, ci = idx % CPP;
+                const int tb = fdiv(p, t.div_phw);
+                const int rr = p - tb * (t.PH * t.PW);
+                const int py = fdiv(rr, t.div_pw), px = rr - py * t.PW;
+                int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
+                const int b = b0 + tb;
+                if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix))
+                    v = *(const u32x4*)(xp + ((size_t)b * a.x_img_pitch + (size_t)(iy * a.x_row_pitch + ix * a.Cin) +
+                                              chunk * CK + ci * (16 / ES)));
+            }
+            pv[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < GIT; ++i) {
+            const int idx = tid + 256 * i;
+            const int q = idx / GPR, ci = idx % GPR;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < t.npx) {
+                int tb, ty, tx;
+                tile_px(t, q, tb, ty, tx);
+                const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+                const int col = n0 + ci * (16 / ES);
+                if (b < a.B && oy < a.OH && ox < a.OW && col + (16 / ES) <= a.dy_cols)
+                    v = *(const u32x4*)(gp + ((size_t)(b * a.OH + oy) * a.OW + ox) * a.dy_ld + col);
+            }
+            gv[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nitems) *(u32x4*)(Ps + (idx / CPP) * PP + (idx % CPP) * 16) = pv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < GIT; ++i) {
+            const int idx = tid + 256 * i;
+            *(u32x4*)(Gs + (idx / GPR) * PG + (idx % GPR) * 16) = gv[i];
+        }
+    };
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+
+    // tap range of this wave; taps past the end are clamped to the last one (their products are
+    // computed and dropped) so that the inner loop stays branch-free and the LDS reads of all taps
+    // of a sub-step are in flight together
+    const int tap0 = wt * TPW;
+    int toff[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int tap = min(tap0 + tt, a.T - 1);
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        toff[tt] = (kh * t.PW + kw) * PP;
+    }
+    auto g_addr = [&](int q) -> const char* { return Gs + q * PG; };
+    auto p_addr = [&](int q) -> const char* {
+        if (q >= t.npx) q = 0;
+        int tb, ty, tx;
+        tile_px(t, q, tb, ty, tx);
+        return Ps + ((tb * t.PH + ty) * t.PW + tx) * PP;
+    };
+    const int nsub = (t.npx + 15) / 16;
+
+    if (tl_beg < tl_end) load_tile(tl_beg);
+    for (int tl = tl_beg; tl < tl_end; ++tl) {
+        __syncthreads();                     // everyone is done reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (tl + 1 < tl_end) load_tile(tl + 1);
+
+        for (int s = 0; s < nsub; ++s) {
+            const frag gf = TrGather<T>::ld(g_addr, s * 16, wn * 32, lane);
+            // LDS addresses of this lane's pixels at tap (0, 0), shared by every tap
+            const char* prow[TrGather<T>::NADDR];
+            TrGather<T>::rows(p_addr, s * 16, lane, prow);
+            frag xf[TPW];
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) xf[tt] = TrGather<T>::ld_rows(prow, toff[tt], lane);
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) mma32(acc[tt], gf, xf[tt]);
+        }
+    }
+
+    // partials [split][n][tap * Cin + chunk*32 + c], D[row = n][col = c]
+    float* out = a.ws + (size_t)blockIdx.z * a.n_rows * a.k_ld;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int tap = tap0 + tt;
+        if (tap >= a.T) continue;
+        const int k = tap * a.Cin + chunk * CK + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)n * a.k_ld + k] = acc[tt][r];
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------
+void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x) {
+    t.TB = TB; t.TH = TH; t.TW = TW; t.PH = TH + KH - 1; t.PW = TW + KW - 1;
+    t.npx = TB * TH * TW; t.tiles_x = tiles_x;
+    t.div_tw = make_fastdiv(TW); t.div_thw = make_fastdiv(TH * TW);
+    t.div_pw = make_fastdiv(t.PW); t.div_phw = make_fastdiv(t.PH * t.PW);
+    t.div_tx = make_fastdiv(tiles_x);
+}
+
+bool patch_eligible(const cvg_conv_desc* d) {
+    if (d->stride != 1 || d->tstep_y != 1 || d->tstep_x != 1) return false;
+    if (d->Cin % CK != 0 || d->x_pix_pitch != d->Cin) return false;
+    if (d->ntaps <= 1 || d->ntaps % d->KW != 0) return false;
+    if ((int64_t)d->B * d->x_img_pitch >= (1ll << 31)) return false;
+    return true;
+}
+
+// Smallest number of tiles, then the smallest patch, over all TH x TW <= BM.
+bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int& TB, int& TH, int& TW) {
+    long best_tiles = -1, best_patch = 0;
+    for (int th = 1; th <= OH && th <= BM; ++th)
+        for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
+            const int pp = (th + KH - 1) * (tw + KW - 1);
+            int tb = BM / (th * tw);
+            if (tb > B) tb = B;
+            if (tb > max_patch_px / pp) tb = max_patch_px / pp;
+            if (tb < 1) continue;
+            const long tiles = (long)ceil_div(OH, th) * ceil_div(OW, tw) * ceil_div(B, tb);
+            const long patch = tiles * tb * pp;
+            if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
+                best_tiles = tiles; best_patch = patch; TB = tb; TH = th; TW = tw;
+            }
+        }
+    return best_tiles > 0;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    static size_t granted = 64 * 1024;           // per kernel instantiation
+    if (bytes > granted) {
+        granted = bytes;
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) CVG_FAIL("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <typename T, int WM, int WN, int MI, int NI>
+int launch_patch_fwd(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
+    if (set_lds(patch_fwd<T, WM, WN, MI, NI>, p.lds_bytes)) return -1;
+    dim3 grid(p.tiles_y * p.tiles_x, ceil_div(a.N, WN * NI * 32), p.groups);
+    patch_fwd<T, WM, WN, MI, NI><<<grid, 256, p.lds_bytes, s>>>(a);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int WN, int WT, int TPW>
+int launch_patch_wgrad(const PatchWgradPlan& p, const PatchWgradArgs& a, hipStream_t s) {
+    if (set_lds(patch_wgrad<T, WN, WT, TPW>, p.lds_bytes)) return -1;
+    dim3 grid(p.nchunks, p.n_tiles, p.nsplit);
+    patch_wgrad<T, WN, WT, TPW><<<grid, 256, p.lds_bytes, s>>>(a);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
+    p.ok = 0;
+    if (!patch_eligible(d)) return;
+    const int es = d->dtype == CVG_BF16 ? 2 : 4;
+    p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
+    p.BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
+    p.BM = d->N > 64 ? 128 : 256;
+    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, 512, p.TB, p.TH, p.TW)) return;
+    p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
+    p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
+    p.patch_px = p.TB * p.PH * p.PW;
+    p.nchunks = d->Cin / CK;
+    // use it only when the tiling wastes little of the MFMA work
+    const double eff = (double)d->B * d->OH * d->OW / ((double)p.tiles_y * p.tiles_x * p.groups * p.BM);
+    if (eff < 0.5 || p.groups > 65535) return;
+    const int patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
+    p.lds_bytes = 2 * (size_t)patch_bytes;
+    p.ok = 1;
+}
+
+int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
+                     const float* bias, const float* cbias, const int32_t* labels, const void* res,
+                     const void* gate, hipStream_t s) {
+    PatchFwdArgs a;
+    const int es = d->dtype == CVG_BF16 ? 2 : 4;
+    a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels; a.res = res; a.gate = gate;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
+    a.off_y = d->off_y; a.off_x = d->off_x; a.pad_mode = d->pad_mode; a.KW = p.KW; a.T = p.T;
+    a.OH = d->OH; a.OW = d->OW; a.N = d->N;
+    a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
+    a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
+    a.nchunks = p.nchunks; a.patch_px = p.patch_px;
+    a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
+    fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
+    // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
+    // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
+    if (d->dtype == CVG_BF16) {
+        if (p.BN == 128) return launch_patch_fwd<bf16, 1, 4, 4, 1>(p, a, s);
+        if (p.BN == 64) return launch_patch_fwd<bf16, 2, 2, 4, 1>(p, a, s);
+        return launch_patch_fwd<bf16, 4, 1, 2, 1>(p, a, s);
+    }
+    if (p.BN == 128) return launch_patch_fwd<float, 1, 4, 4, 1>(p, a, s);
+    if (p.BN == 64) return launch_patch_fwd<float, 2, 2, 4, 1>(p, a, s);
+    return launch_patch_fwd<float, 4, 1, 2, 1>(p, a, s);
+}
+
+int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap* map, const float* canonical,
+                      void* packed, hipStream_t s) {
+    const int64_t n = (int64_t)d->w_rows * p.nchunks * p.T * 2 * 16;
+    CVG_CHECK((int64_t)p.nchunks * p.T * CK <= d->w_ld, "patch_pack: packed buffer too small");
+    if (d->dtype == CVG_BF16)
+        patch_pack<bf16><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (bf16*)packed, *map, d->w_rows, p.nchunks, p.T, d->Cin);
+    else
+        patch_pack<float><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (float*)packed, *map, d->w_rows, p.nchunks, p.T, d->Cin);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
+    p.ok = 0;
+    if (!patch_eligible(d)) return;
+    const int es = d->dtype == CVG_BF16 ? 2 : 4;
+    p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
+    if (d->N > 64) { p.WN = 4; p.WT = 1; }
+    else if (d->N > 32) { p.WN = 2; p.WT = 2; }
+    else { p.WN = 1; p.WT = 4; }
+    p.BNW = 32 * p.WN;
+    const int tpw = ceil_div(p.T, p.WT);
+    if (!(tpw == 9 || tpw == 5 || tpw == 3 || tpw == 13)) return;       // instantiated tap counts
+    const int bmp = es == 2 ? 256 : 128;
+    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, bmp, 2 * bmp, p.TB, p.TH, p.TW)) return;
+    p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
+    p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
+    p.ntiles = p.tiles_y * p.tiles_x * p.groups;
+    p.patch_px = p.TB * p.PH * p.PW;
+    p.nchunks = d->Cin / CK;
+    p.n_tiles = ceil_div(d->N, p.BNW);
+    const double eff = (double)d->B * d->OH * d->OW / ((double)p.ntiles * bmp);
+    if (eff < 0.5) return;
+    int want = ceil_div(512, p.nchunks * p.n_tiles);
+    if (want > p.ntiles) want = p.ntiles;
+    if (want < 1) want = 1;
+    p.tiles_per_split = ceil_div(p.ntiles, want);
+    p.nsplit = ceil_div(p.ntiles, p.tiles_per_split);
+    if (p.nsplit > 65535) return;
+    const int gw = p.BNW * es;
+    const int pg = (gw == 64 || es == 4) ? gw : gw + 64;
+    p.lds_bytes = (size_t)((p.patch_px * CK * es + 255) & ~255) + (size_t)bmp * pg;
+    p.ws_bytes = (size_t)p.nsplit * (p.n_tiles * p.BNW) * ((size_t)p.T * d->Cin) * sizeof(float);
+    p.ok = 1;
+}
+
+int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const void* x, const void* dy, int dy_ld,
+                       const cvg_wmap* map, float* grad, int accumulate, float* ws, hipStream_t s) {
+    PatchWgradArgs a;
+    a.x = x; a.dy = dy; a.ws = ws;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
+    a.off_y = d->off_y; a.off_x = d->off_x; a.pad_mode = d->pad_mode; a.KW = p.KW; a.T = p.T;
+    a.OH = d->OH; a.OW = d->OW; a.dy_ld = dy_ld; a.dy_cols = dy_ld;
+    a.patch_px = p.patch_px; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
+    a.tiles_per_group = p.tiles_y * p.tiles_x;
+    a.n_rows = p.n_tiles * p.BNW; a.k_ld = p.T * d->Cin;
+    fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
+    a.div_tpg = make_fastdiv(a.tiles_per_group);
+    const int tpw = ceil_div(p.T, p.WT);
+    int rc = -1;
+    if (d->dtype == CVG_BF16) {
+        if (p.WN == 4 && tpw == 9) rc = launch_patch_wgrad<bf16, 4, 1, 9>(p, a, s);
+        else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5>(p, a, s);
+        else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<bf16, 1, 4, 3>(p, a, s);
+        else if (p.WN == 1 && tpw == 13) rc = launch_patch_wgrad<bf16, 1, 4, 13>(p, a, s);
+        else CVG_FAIL("patch_wgrad: no kernel for WN %d taps/wave %d", p.WN, tpw);
+    } else {
+        if (p.WN == 4 && tpw == 9) rc = launch_patch_wgrad<float, 4, 1, 9>(p, a, s);
+        else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<float, 2, 2, 5>(p, a, s);
+        else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<float, 1, 4, 3>(p, a, s);
+        else if (p.WN == 1 && tpw == 13) rc = launch_patch_wgrad<float, 1, 4, 13>(p, a, s);
+        else CVG_FAIL("patch_wgrad: no kernel for WN %d taps/wave %d", p.WN, tpw);
+    }
+    if (rc) return rc;
+    const int64_t n = (int64_t)map->n_valid * a.k_ld;
+    wgrad_reduce<<<ceil_div(n, 256), 256, 0, s>>>(ws, grad, *map, a.n_rows, a.k_ld, p.nsplit, accumulate);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}

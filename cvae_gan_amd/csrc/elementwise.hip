@@ -76,13 +76,36 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     }
 }
 
-__global__ void stats_finalize(const float* __restrict__ ws, int nblk, int M, int C, float* __restrict__ stats,
-                               float* running_mean, float* running_var, long long* nbt) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += ws[(size_t)b * C + c]; ss += ws[((size_t)nblk + b) * C + c]; }
+// Partial sums [2][nblk][C] -> per-channel totals.  One 256-thread block per 16 channels:
+// thread (lane = t / 16, ch = t % 16) strides the partial blocks, then the 16 lanes meet in LDS.
+__device__ __forceinline__ void sum_partials(const float* __restrict__ ws, int nblk, int C, int c0, double& s,
+                                             double& ss, bool want_ss) {
+    __shared__ double red[2][16][16];
+    const int ch = threadIdx.x & 15, ln = threadIdx.x >> 4;
+    const int c = c0 + ch;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = ln; k < nblk; k += 16) {
+            a += ws[(size_t)k * C + c];
+            if (want_ss) b += ws[((size_t)nblk + k) * C + c];
+        }
+    red[0][ln][ch] = a;
+    red[1][ln][ch] = b;
+    __syncthreads();
+    s = ss = 0.0;
+    if (ln == 0) {
+        for (int k = 0; k < 16; ++k) { s += red[0][k][ch]; ss += red[1][k][ch]; }
+    }
+}
+
+__global__ void __launch_bounds__(256) stats_finalize(const float* __restrict__ ws, int nblk, int M, int C,
+                                                      float* __restrict__ stats, float* running_mean,
+                                                      float* running_var, long long* nbt) {
+    double s, ss;
+    sum_partials(ws, nblk, C, blockIdx.x * 16, s, ss, true);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
     const double mean = s / M;
     double var = ss / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -103,14 +126,14 @@ __global__ void eval_stats(const float* rm, const float* rv, int C, float* stats
 }
 
 // sums partials; out0[map(c)] = sum of partial 0, out1[c] = sum of partial 1 (optional)
-__global__ void sum_finalize(const float* __restrict__ ws, int nblk, int C, float* out0, float* out1, int md, int ma,
-                             int mb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, t = 0.f;
-    for (int b = 0; b < nblk; ++b) { s += ws[(size_t)b * C + c]; if (out1) t += ws[((size_t)nblk + b) * C + c]; }
-    out0[(c / md) * ma + (c % md) * mb] = s;
-    if (out1) out1[c] = t;
+__global__ void __launch_bounds__(256) sum_finalize(const float* __restrict__ ws, int nblk, int C, float* out0,
+                                                    float* out1, int md, int ma, int mb) {
+    double s, t;
+    sum_partials(ws, nblk, C, blockIdx.x * 16, s, t, out1 != nullptr);
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
+    out0[(c / md) * ma + (c % md) * mb] = (float)s;
+    if (out1) out1[c] = (float)t;
 }
 
 // ---- BatchNorm + LeakyReLU apply -------------------------------------------------------
@@ -615,7 +638,7 @@ int red_threads(int C) { const int CC = C / 8; return CC * (256 / CC); }
 int red_blocks(int M, int C) {
     const int RL = 256 / (C / 8);
     int nb = ceil_div(M, (int64_t)RL * 8);
-    return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
 }
 int check_rows(const char* who, int M, int C) {
     CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && C <= 1024, "%s: M %d C %d (C must be a multiple of 8, <= 1024)", who, M, C);
@@ -650,7 +673,7 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
     DISPATCH(dtype, colreduce<T, RED_STATS><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    stats_finalize<<<grid1(C, 128), 128, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
+    stats_finalize<<<grid1(C, 16), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -684,7 +707,7 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
     RedArgs a = {x, dy, y, stats, ws, M, C, C, red_blocks(M, C), C};
     DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    sum_finalize<<<grid1(C, 128), 128, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
+    sum_finalize<<<grid1(C, 16), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
     CVG_LAUNCH_CHECK();
     const int RL = 256 / (C / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
@@ -704,7 +727,7 @@ int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, f
     RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
     DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, C / Cb), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    sum_finalize<<<grid1(C, 128), 128, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
+    sum_finalize<<<grid1(C, 16), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
     CVG_LAUNCH_CHECK();
     return 0;
 }

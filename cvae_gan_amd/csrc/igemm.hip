@@ -11,7 +11,10 @@
 // workgroup and 64x64 (or 64x32 / 32x32) per-wave tiles of 32x32 MFMA blocks.
 // T = bf16 uses v_mfma_f32_32x32x16_bf16; T = float uses v_mfma_f32_32x32x2_f32,
 // which is an exact f32 fma chain and serves as the tight-tolerance parity mode.
+#include <stdlib.h>
 #include "common.h"
+#include "gemm_util.h"
+#include "conv_patch.h"
 
 namespace {
 
@@ -251,37 +254,6 @@ __global__ void splitk_finish(const float* __restrict__ ws, T* __restrict__ y, c
 // ================================================================================
 // weight-gradient kernel
 // ================================================================================
-// LDS tiles keep the natural [pixel][channel] order; the MFMA operands need
-// [channel][8 consecutive pixels], i.e. a transpose.  bf16 uses the hardware
-// transposing read ds_read_b64_tr_b16: per 16-lane group it fetches a 4-pixel x
-// 16-channel block (lane 4q+p supplies the address of pixel q, channels 4p..4p+3)
-// and hands lane i channel i of the four pixels.  f32 reads single dwords.
-template <typename T> struct TrLoad;
-template <> struct TrLoad<bf16> {
-    __device__ static __forceinline__ bf16x8 ld(const char* base, int pitch, int m0, int c0, int lane) {
-        const int i = lane & 15, q = i >> 2, p = i & 3, blk = (lane >> 4) & 1, h = lane >> 5;
-        const char* ptr = base + (m0 + 8 * h + q) * pitch + (c0 + 16 * blk + 4 * p) * 2;
-        typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)ptr);
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(ptr + 4 * pitch));
-        bf16x8 r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
-        return r;
-    }
-};
-template <> struct TrLoad<float> {
-    __device__ static __forceinline__ f32x8 ld(const char* base, int pitch, int m0, int c0, int lane) {
-        const int l31 = lane & 31, h = lane >> 5;
-        f32x8 r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = *(const float*)(base + (m0 + 2 * j + h) * pitch + (c0 + l31) * 4);
-        return r;
-    }
-};
-// For T = float the slot (h, j) holds pixel 2j+h, for bf16 pixel 8h+j; both operands
-// of one MFMA use the same loader, so the products pair up correctly.
-
 template <typename T, int BNW, int BKW, int WN, int WK>
 __global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
     constexpr int VEC = Elem<T>::VEC;
@@ -404,33 +376,6 @@ __global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
         }
 }
 
-// ---- canonical <-> GEMM layout map ---------------------------------------------
-__device__ __forceinline__ int wmap_index(const cvg_wmap& m, int n, int k) {
-    if (n >= m.n_valid) return -1;
-    const int j = k / m.kd, c = k - j * m.kd;
-    if (c >= m.kc_valid || j >= m.ntaps) return -1;
-    int t = j;
-    if (m.tap_mode == 1) t = m.ntaps - 1 - j;
-    else if (m.tap_mode == 2) t = m.tap_table[j];
-    if (t < 0) return -1;
-    const int nq = n / m.nd, nr = n - nq * m.nd;
-    return nq * m.na + nr * m.nb + t * m.ka + c * m.kb;
-}
-
-__global__ void wgrad_reduce(const float* __restrict__ ws, float* __restrict__ grad, const cvg_wmap map,
-                             int n_rows, int k_ld, int nsplit, int accumulate) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)map.n_valid * k_ld) return;
-    const int n = (int)(idx / k_ld), k = (int)(idx % k_ld);
-    const int ci = wmap_index(map, n, k);
-    if (ci < 0) return;
-    float s = 0.f;
-    const size_t stride = (size_t)n_rows * k_ld;
-    const float* p = ws + (size_t)n * k_ld + k;
-    for (int z = 0; z < nsplit; ++z) s += p[z * stride];
-    grad[ci] = accumulate ? grad[ci] + s : s;
-}
-
 template <typename T>
 __global__ void weight_pack(const float* __restrict__ canonical, T* __restrict__ packed, const cvg_wmap map,
                             int rows, int ld) {
@@ -443,6 +388,11 @@ __global__ void weight_pack(const float* __restrict__ canonical, T* __restrict__
 
 // ---- host side -------------------------------------------------------------------
 int elem_size(int dtype) { return dtype == CVG_BF16 ? 2 : 4; }
+
+bool patch_enabled() {
+    static const bool on = getenv("CVG_NO_PATCH") == nullptr;     // A/B switch for benchmarking
+    return on;
+}
 
 int make_geom(const cvg_conv_desc* d, Geom& g) {
     CVG_CHECK(d->dtype == CVG_F32 || d->dtype == CVG_BF16, "conv: bad dtype %d", d->dtype);
@@ -579,20 +529,29 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     a.ws = (float*)ws; a.N = d->N; a.w_ld = d->w_ld;
     a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
+    hipStream_t s = (hipStream_t)stream;
+    if (patch_enabled()) {
+        PatchPlan pp;
+        patch_fwd_plan(d, pp);
+        if (pp.ok) return patch_fwd_launch(d, pp, x, w, y, bias, cbias, labels, res, gate, s);
+    }
     a.nk_total = ceil_div(a.g.Kvalid, BK);
     a.ksplit = fwd_ksplit(d, a.g.M, dense);
     a.nk_per_split = ceil_div(a.nk_total, a.ksplit);
     a.ksplit = ceil_div(a.nk_total, a.nk_per_split);
     if (a.ksplit > 1)
         CVG_CHECK(ws && ws_bytes >= (size_t)a.ksplit * a.g.M * d->N * sizeof(float), "conv_fwd: workspace too small");
-    hipStream_t s = (hipStream_t)stream;
     return d->dtype == CVG_BF16 ? launch_fwd<bf16>(d, a, s) : launch_fwd<float>(d, a, s);
 }
 
 size_t cvg_conv_wgrad_workspace(const cvg_conv_desc* d) {
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
     WgradPlan p = plan_wgrad(d, (int)M);
-    return (size_t)p.nsplit * p.n_rows * p.k_ld * sizeof(float);
+    size_t bytes = (size_t)p.nsplit * p.n_rows * p.k_ld * sizeof(float);
+    PatchWgradPlan wp;
+    patch_wgrad_plan(d, wp);
+    if (wp.ok && wp.ws_bytes > bytes) bytes = wp.ws_bytes;
+    return bytes;
 }
 
 int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_t dy_ld, const cvg_wmap* map,
@@ -601,6 +560,15 @@ int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_
     if (make_geom(d, a.g)) return -1;
     CVG_CHECK(x && dy && map && grad && ws, "conv_wgrad: null tensor");
     CVG_CHECK(dy_ld % 8 == 0 && dy_ld >= d->N, "conv_wgrad: dy_ld %d", dy_ld);
+    CVG_CHECK(map->kd > 0 && map->nd > 0, "conv_wgrad: bad map");
+    if (patch_enabled()) {
+        PatchWgradPlan wp;
+        patch_wgrad_plan(d, wp);
+        if (wp.ok) {
+            CVG_CHECK(ws_bytes >= wp.ws_bytes, "conv_wgrad: workspace too small");
+            return patch_wgrad_launch(d, wp, x, dy, dy_ld, map, grad, accumulate, (float*)ws, (hipStream_t)stream);
+        }
+    }
     WgradPlan p = plan_wgrad(d, a.g.M);
     CVG_CHECK(ws_bytes >= (size_t)p.nsplit * p.n_rows * p.k_ld * sizeof(float), "conv_wgrad: workspace too small");
     CVG_CHECK(map->n_valid <= p.n_rows && map->kd > 0 && map->nd > 0, "conv_wgrad: bad map");
@@ -615,13 +583,19 @@ int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_
     return 0;
 }
 
-int cvg_weight_pack(const cvg_wmap* map, const float* canonical, void* packed, int32_t rows, int32_t ld,
-                    int32_t dtype, cvg_stream stream) {
-    CVG_CHECK(map && canonical && packed && rows > 0 && ld > 0, "weight_pack: bad args");
+int cvg_weight_pack(const cvg_conv_desc* d, const cvg_wmap* map, const float* canonical, void* packed,
+                    cvg_stream stream) {
+    CVG_CHECK(d && map && canonical && packed && d->w_rows > 0 && d->w_ld > 0, "weight_pack: bad args");
     CVG_CHECK(map->kd > 0 && map->nd > 0, "weight_pack: bad map");
     hipStream_t s = (hipStream_t)stream;
+    if (patch_enabled()) {
+        PatchPlan pp;
+        patch_fwd_plan(d, pp);
+        if (pp.ok) return patch_pack_launch(d, pp, map, canonical, packed, s);
+    }
+    const int rows = d->w_rows, ld = d->w_ld;
     const int64_t n = (int64_t)rows * ld;
-    if (dtype == CVG_BF16) weight_pack<bf16><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (bf16*)packed, *map, rows, ld);
+    if (d->dtype == CVG_BF16) weight_pack<bf16><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (bf16*)packed, *map, rows, ld);
     else weight_pack<float><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (float*)packed, *map, rows, ld);
     CVG_LAUNCH_CHECK();
     return 0;

@@ -179,7 +179,7 @@ class _Gemm:
         eng._ws_bytes = max(eng._ws_bytes, ops.conv_fwd_workspace(desc))
 
     def pack(self, eng):
-        ops.weight_pack(self.wmap, eng.params[self.key], self.w, self.desc.w_rows, self.desc.w_ld)
+        ops.weight_pack(self.desc, self.wmap, eng.params[self.key], self.w)
 
 
 class Engine:

@@ -50,8 +50,9 @@ def conv_wgrad_workspace(desc):
     return int(lib.cvg_conv_wgrad_workspace(C.byref(desc)))
 
 
-def weight_pack(wmap, canonical, packed, rows, ld):
-    check(lib.cvg_weight_pack(C.byref(wmap), ptr(canonical), ptr(packed), rows, ld, dt(packed), stream()))
+def weight_pack(desc, wmap, canonical, packed):
+    assert packed.numel() >= desc.w_rows * desc.w_ld and dt(packed) == desc.dtype
+    check(lib.cvg_weight_pack(C.byref(desc), C.byref(wmap), ptr(canonical), ptr(packed), stream()))
 
 
 def label_bias(w_stem, cbias, cout, y_dim):

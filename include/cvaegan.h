@@ -101,10 +101,12 @@ int    cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int
                       const cvg_wmap* map, float* grad, int32_t accumulate,
                       void* ws, size_t ws_bytes, cvg_stream s);
 
-/* Canonical f32 weights -> kernel layout [rows][ld] in dtype (rows >= n_valid, zero
- * padded).  Runs once per optimiser step per layout.                              */
-int cvg_weight_pack(const cvg_wmap* map, const float* canonical, void* packed,
-                    int32_t rows, int32_t ld, int32_t dtype, cvg_stream s);
+/* Canonical f32 weights -> the layout the kernels chosen for `d` consume, in d->dtype:
+ * row-major [w_rows][w_ld] (k = tap*Cin + c, zero padded) for the gather kernel, MFMA
+ * fragment order for the patch-staged kernel.  packed holds w_rows * w_ld elements.
+ * Runs once per optimiser step per layout.                                          */
+int cvg_weight_pack(const cvg_conv_desc* d, const cvg_wmap* map, const float* canonical,
+                    void* packed, cvg_stream s);
 
 /* Stem label fold (encoder.forward's torch.cat of label planes, networks.py:86,
  * cvae.py:129): cbias[c][n] = sum over the 49 taps of W[n][3 + c][kh][kw].          */

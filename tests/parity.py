@@ -71,9 +71,9 @@ def oracle_pass(case, step=0, state=None):
                 z_mean=mu, z_sigma=sigma, new_stats=new_stats)
 
 
-def engine_pass(case, dtype, step=0):
+def engine_pass(case, dtype, step=0, state=None):
     from cvae_gan_amd.engine import Engine
-    e, d = case.init_state()
+    e, d = state if state is not None else case.init_state()
     st = OrderedDict(e)
     st.update(d)
     eng = Engine(case.P, case.y, case.z, case.B, dtype=dtype, ngf=case.ngf, state=st)
@@ -119,11 +119,14 @@ def engine_tensors(eng):
     return acts, agrads, pgrads
 
 
-def run_parity(name, dtype, step=0):
-    """-> list of (kind, key, rel_err, ref_max, cosine)"""
+def run_parity(name, dtype, step=0, state_fn=None):
+    """-> list of (kind, key, rel_err, ref_max, cosine).  state_fn, if given, edits the initial
+    (encoder, decoder) state dicts before both sides see them."""
     case = Case(name)
-    ref = oracle_pass(case, step)
-    eng = engine_pass(case, dtype, step)
+    st_ref = state_fn(case.init_state()) if state_fn else None
+    st_eng = state_fn(case.init_state()) if state_fn else None
+    ref = oracle_pass(case, step, st_ref)
+    eng = engine_pass(case, dtype, step, st_eng)
     acts, agrads, pgrads = engine_tensors(eng)
     rows = []
     for k, t in ref["acts"].items():
@@ -137,7 +140,7 @@ def run_parity(name, dtype, step=0):
         rows.append(("grad", k, r, m, cosine(pgrads[k], ref["pgrads"][k])))
     got = eng.read_losses()
     for k in ("VAE", "KL", "LL"):
-        rv = float(ref["losses"][k])
+        rv = float(ref["losses"][k].detach())
         rows.append(("loss", k, abs(got[k] - rv) / abs(rv), rv, 1.0))
     r, m = rel_err(eng.z_mean.cpu(), ref["z_mean"])
     rows.append(("act", "z_mean", r, m, 1.0))

@@ -32,7 +32,7 @@ def relmax(a, b):
 
 def pack(ops, wmap, w, desc, dtype):
     packed = torch.zeros(desc.w_rows * desc.w_ld, dtype=dtype, device="cuda")
-    ops.weight_pack(wmap, w.cuda().contiguous(), packed, desc.w_rows, desc.w_ld)
+    ops.weight_pack(desc, wmap, w.cuda().contiguous(), packed)
     return packed
 
 
