@@ -129,6 +129,38 @@ def init_state(P, y_dim, z_dim, seed=0, n_stage=4, ngf=64):
     return out[0], out[1]
 
 
+def arena_layout(P, y_dim, z_dim, n_stage=4, ngf=64):
+    """Flat f32 arena shared by parameters, gradients and AdamW moments.  Tensors are placed in
+    the order in which backward finishes their gradients (decoder tail first, encoder stem
+    last), so that contiguous ranges can be all-reduced while backward is still running."""
+    enc_s, dec_s = param_shapes(P, y_dim, z_dim, n_stage, ngf)
+    shapes = OrderedDict()
+    shapes.update(enc_s)
+    shapes.update(dec_s)
+    trainable = [k for k in shapes if not is_buffer(k)]
+    dec_tr = [k for k in trainable if k.startswith(DP)]
+    enc_tr = [k for k in trainable if k.startswith(EP)]
+
+    def dec_rank(k):
+        if ".fc.0." in k:
+            return 100
+        if ".fc.3." in k:
+            return 99
+        return n_stage + 1 - int(k[len(DP) + 5:].split(".")[0])      # conv.N...
+
+    def enc_rank(k):
+        if ".fc." in k:
+            return 3 - int(k.split(".fc.")[1].split(".")[0])
+        return 100 - int(k[len(EP) + 5:].split(".")[0])
+
+    order = sorted(dec_tr, key=dec_rank) + sorted(enc_tr, key=enc_rank)
+    offs, n = {}, 0
+    for k in order:
+        offs[k] = n
+        n += _rup(int(torch.Size(shapes[k]).numel()), 4)
+    return dict(enc_keys=list(enc_s), dec_keys=list(dec_s), shapes=shapes, order=order, offsets=offs, numel=n)
+
+
 # ------------------------------------------------------------------------------------
 # descriptors
 # ------------------------------------------------------------------------------------
@@ -184,7 +216,9 @@ class _Gemm:
 
 class Engine:
     def __init__(self, pix_dim, y_dim, z_dim, batch, dtype=torch.bfloat16, ngf=64, n_stage=4,
-                 device="cuda", seed=0, state=None):
+                 device="cuda", seed=0, state=None, share=None):
+        """share: another Engine of the same network; this one then aliases its parameter,
+        gradient and optimiser arenas and BatchNorm buffers (only the batch size differs)."""
         assert pix_dim % (2 ** n_stage) == 0, "pix_dim must be a multiple of %d" % (2 ** n_stage)
         assert z_dim % 4 == 0, "z_dim must be a multiple of 4 (channel vectors are 8 wide)"
         assert ngf % 8 == 0 and (ngf & (ngf - 1)) == 0, "ngf must be a power of two >= 8"
@@ -196,47 +230,39 @@ class Engine:
         self.step_count = 0
         self.training = True
         self.grad_ready = None      # callable(stage) -> None, see cvae_gan_amd/ddp.py
+        self._share = share
         self._build_params(seed, state)
         self._build_encoder()
         self._build_decoder()
         self._build_workspaces()
+        if share is not None:        # one optimiser state for all engines of the network
+            self.step_dev, self.bc_dev = share.step_dev, share.bc_dev
         self._packed_version = -1
-        self._param_version = 0
+
+    # canonical parameters may be written by any engine sharing the arenas or by an outside
+    # optimiser; one counter tells every engine when its packed shadows are stale
+    @property
+    def _param_version(self):
+        return self._vers[0]
+
+    @_param_version.setter
+    def _param_version(self, v):
+        self._vers[0] = v
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self, seed, state):
-        enc_s, dec_s = param_shapes(self.P, self.y, self.z, self.n_stage, self.ngf)
-        self.enc_keys, self.dec_keys = list(enc_s), list(dec_s)
-        shapes = OrderedDict()
-        shapes.update(enc_s)
-        shapes.update(dec_s)
-        self.shapes = shapes
-        # arena order = order in which backward finishes the gradients (decoder tail first,
-        # encoder stem last), so that contiguous ranges can be all-reduced while backward runs
-        trainable = [k for k in shapes if not is_buffer(k)]
-        dec_tr = [k for k in trainable if k.startswith(DP)]
-        enc_tr = [k for k in trainable if k.startswith(EP)]
-
-        def dec_rank(k):
-            if ".fc.0." in k:
-                return 100
-            if ".fc.3." in k:
-                return 99
-            return self.n_stage + 1 - int(k[len(DP) + 5:].split(".")[0])      # conv.N...
-
-        def enc_rank(k):
-            if ".fc." in k:
-                return 3 - int(k.split(".fc.")[1].split(".")[0])
-            return 100 - int(k[len(EP) + 5:].split(".")[0])
-
-        order = sorted(dec_tr, key=dec_rank) + sorted(enc_tr, key=enc_rank)
-        self.arena_order = order
-        offs, n = {}, 0
-        for k in order:
-            offs[k] = n
-            n += _rup(int(torch.Size(shapes[k]).numel()), 4)
-        self.arena_offsets, self.arena_numel = offs, n
+        lay = arena_layout(self.P, self.y, self.z, self.n_stage, self.ngf)
+        self.enc_keys, self.dec_keys, self.shapes = lay["enc_keys"], lay["dec_keys"], lay["shapes"]
+        self.arena_order, self.arena_offsets, self.arena_numel = lay["order"], lay["offsets"], lay["numel"]
+        shapes, order, offs, n = self.shapes, self.arena_order, self.arena_offsets, self.arena_numel
         dev = self.device
+        sh = self._share
+        if sh is not None:
+            assert (sh.P, sh.y, sh.z, sh.ngf, sh.n_stage) == (self.P, self.y, self.z, self.ngf, self.n_stage)
+            self.p_arena, self.g_arena, self.m_arena, self.v_arena = sh.p_arena, sh.g_arena, sh.m_arena, sh.v_arena
+            self.params, self.grads, self.buffers, self._vers = sh.params, sh.grads, sh.buffers, sh._vers
+            return
+        self._vers = [0]
         self.p_arena = torch.zeros(n, dtype=torch.float32, device=dev)
         self.g_arena = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m_arena = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -269,7 +295,7 @@ class Engine:
                     self.buffers[k].copy_(v)
                 else:
                     raise KeyError("unexpected key %r" % k)
-        self._param_version = getattr(self, "_param_version", 0) + 1
+        self._param_version += 1
 
     def state_dict(self, which):
         """'encoder' / 'decoder' checkpoint dict with the reference's keys, on the CPU."""

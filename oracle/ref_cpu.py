@@ -360,3 +360,26 @@ def train_step(st, x, labels, eps, drop_mask, y_dim, batch_size, lr):
     return dict(VAE=vae.detach(), KL=kl.detach(), LL=ll.detach(), dec=dec.detach(),
                 z_mean=mu.detach(), z_sigma=sigma.detach(), h_enc=h_enc.detach(),
                 grads=grads)
+
+
+def dp_forward_backward(enc_sd, dec_sd, x, labels, eps, drop_mask, y_dim, batch_size, n_replica):
+    """Gradient of one step under the reference's nn.DataParallel wrapping
+    (models/cvae.py:57-59): the batch is split into n_replica equal chunks, encoder and
+    decoder run per chunk (so BatchNorm normalises each chunk by its own statistics), the
+    sampler and both losses see the gathered full batch.  Returns (losses, grads)."""
+    params = {}
+    for sd in (enc_sd, dec_sd):
+        for k, t in sd.items():
+            if not is_buffer(k):
+                sd[k] = t.detach().clone().requires_grad_(True)
+                params[k] = sd[k]
+    z_dim = eps.shape[1]
+    xs, ls = x.chunk(n_replica), labels.chunk(n_replica)
+    h = torch.cat([encoder_forward(enc_sd, xc, label_planes(lc, y_dim, x.shape[-1], x.dtype), True, None)
+                   for xc, lc in zip(xs, ls)])
+    z, mu, sigma = sample_latent(h, eps, z_dim)
+    dec = torch.cat([decoder_forward(dec_sd, zc, one_hot(lc, y_dim, x.dtype), mc, True)
+                     for zc, lc, mc in zip(z.chunk(n_replica), ls, drop_mask.chunk(n_replica))])
+    vae, kl, ll = losses(dec, x, mu, sigma, batch_size)
+    grads = torch.autograd.grad(vae, list(params.values()))
+    return dict(VAE=vae.detach(), KL=kl.detach(), LL=ll.detach()), dict(zip(params.keys(), grads))

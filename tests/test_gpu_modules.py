@@ -1,0 +1,93 @@
+"""The drop-in module surface (encoder / decoder / CVAE_T / latent_loss) driven exactly like
+the reference's training loop (models/cvae.py:125-157): torch losses on the module outputs,
+loss.backward(), torch.optim.AdamW -- against the fixture recorded from the reference."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Case
+from oracle.fixtures import compare
+
+pytestmark = pytest.mark.gpu
+
+
+class Args:
+    pass
+
+
+def make(case, dtype="f32"):
+    from cvae_gan_amd import networks as N
+    a = Args()
+    a.z_dim, a.y_dim, a.pix_dim, a.device, a.dtype, a.ngf = case.z, case.y, case.P, torch.device("cuda"), dtype, case.ngf
+    enc, dec = N.encoder(a), N.decoder(a)
+    e, d = case.init_state()
+    enc.load_state_dict(e)
+    dec.load_state_dict(d)
+    model = N.CVAE_T(a, enc, dec)
+    return N, enc, dec, model
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    c = Case("tiny_p16_ngf8")
+    N, enc, dec, model = make(c)
+    e, d = c.init_state()
+    assert list(enc.state_dict().keys()) == list(e.keys())
+    assert list(dec.state_dict().keys()) == list(d.keys())
+    for k, v in enc.state_dict().items():
+        assert tuple(v.shape) == tuple(e[k].shape), k
+
+
+@pytest.mark.parametrize("name", ["tiny_p16_ngf8", "ragged_p32_ngf8"])
+def test_reference_style_training_loop(name):
+    c = Case(name)
+    N, enc, dec, model = make(c)
+    opt = torch.optim.AdamW(model.parameters(), lr=c.lr, betas=(0.5, 0.999), eps=1e-8)   # cvae.py:67
+    mse = torch.nn.MSELoss()
+    model.train()
+    x, labels, eps, mask = c.inputs(0)
+    planes = torch.zeros(c.B, c.y, c.P, c.P)
+    planes[torch.arange(c.B), labels] = 1
+    yvec = torch.zeros(c.B, c.y)
+    yvec[torch.arange(c.B), labels] = 1
+    x, planes, yvec = x.cuda(), planes.cuda(), yvec.cuda()
+
+    # the reference draws eps with numpy inside _sample_latent and the dropout mask with torch's
+    # RNG; feed the fixture's values through the same two doors
+    orig_normal = np.random.normal
+    np.random.normal = lambda *a, **k: eps.double().numpy()
+    eng = enc._pair.engine(c.B)
+    eng.random_mask = lambda seed=None: eng.set_mask(mask)
+    try:
+        out = model(x, planes, yvec)
+    finally:
+        np.random.normal = orig_normal
+    opt.zero_grad()
+    kl = N.latent_loss(model.z_mean, model.z_sigma) / c.bs_flag          # cvae.py:137
+    ll = mse(out, x) / c.bs_flag * 50.0                                   # cvae.py:139
+    vae = ll + kl
+    vae.backward()
+    for k, v in (("VAE", vae), ("KL", kl), ("LL", ll)):
+        ref = float(c.npz["s0/" + k])
+        assert abs(float(v) - ref) <= 2e-5 * abs(ref), (k, float(v), ref)
+    ok, msg = compare(c.npz, "s0/dec", out.detach().cpu().numpy(), 1e-3, 3e-4)
+    assert ok, msg
+    zero_grad = {"encoder.module.conv.1.bias", "encoder.module.fc.0.bias"}
+    for mod in (enc, dec):
+        for k, p in mod.named_parameters():
+            if k in zero_grad:
+                continue
+            ok, msg = compare(c.npz, "s0/grad/" + k, p.grad.detach().cpu().numpy(), 2e-3, 1e-6, 1e-3)
+            assert ok, msg
+    opt.step()
+    # eval-mode decoder-only sampling (cvae.py:167-171) after the step, different batch size
+    model.eval()
+    enc.eval()
+    dec.eval()
+    with torch.no_grad():
+        zs = torch.from_numpy(c.npz["eval/z"]).cuda()
+        ys = torch.from_numpy(c.npz["eval/y"]).cuda()
+        samples = dec(zs[:3], ys[:3])
+    assert samples.shape == (3, 3, c.P, c.P) and bool(torch.isfinite(samples).all())
+    assert float(samples.abs().max()) <= 1.0
