@@ -32,6 +32,7 @@ struct PatchFwdArgs {
     int OH, OW, N;
     int y_img_pitch, y_row_pitch, y_pix_pitch, oy_mul, oy_off, ox_mul, ox_off;
     int nchunks, patch_px, patch_bytes;
+    int lane_perm;                          // tile rows are 16 pixels wide: use lane_pixel()
     TileGeom t;
 };
 
@@ -54,18 +55,36 @@ __device__ __forceinline__ void tile_px(const TileGeom& t, int q, int& tb, int& 
     tx = r - ty * t.TW;
 }
 
+// ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (likewise for
+// the upper half-wave).  With 16-pixel tile rows the natural lane -> pixel order puts pixels of
+// two different tile rows in one group and they collide on LDS banks (the rows are 18 or 22 patch
+// pixels apart).  This order gives each group 16 pixels of ONE tile row: conflict-free.
+__device__ __forceinline__ int lane_pixel(int l31, int permute) {
+    if (!permute) return l31;
+    if (l31 < 4) return l31;
+    if (l31 < 12) return l31 + 12;          // 4..11  -> 16..23
+    if (l31 < 16) return l31 - 8;           // 12..15 -> 4..7
+    if (l31 < 20) return l31 + 8;           // 16..19 -> 24..27
+    if (l31 < 28) return l31 - 12;          // 20..27 -> 8..15
+    return l31;                             // 28..31 -> 28..31
+}
+
 // ======================================================================================
 // forward
 // ======================================================================================
-template <typename T, int WM, int WN, int MI, int NI>
-__global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
+template <typename T, int WM, int WN, int MI, int NI, int KWT>
+__global__ void __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) patch_fwd(const PatchFwdArgs a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int CPP = CK * ES / 16;            // 16-byte pieces per patch pixel
     constexpr int PITCH = CK * ES + 16;          // conflict-free ds_read_b128 across pixels
     constexpr int NIT = 2 * CPP;                 // patch pieces per thread (patch_px <= 512)
     constexpr int WTM = MI * 32, WTN = NI * 32, BN = WN * WTN;
     constexpr int FRAG = 64 * 8;                 // elements per packed fragment (one wave-load)
-    constexpr int D = 4;                         // weight steps in flight per wave
+    // Taps unrolled per loop body = weight steps in flight per wave: all 9 taps of a 3x3 kernel,
+    // one tap row of a 7x7 kernel.  The body is branch-free and every load in it is
+    // unconditional, so the compiler can count outstanding loads exactly and a step only waits
+    // for its own fragments (issued TU steps, i.e. > 2000 cycles of MFMA work, earlier).
+    constexpr int TU = (KWT == 3 && sizeof(T) == 2) ? 9 : KWT;   // f32 fragments are twice as wide: one tap row
     typedef typename Elem<T>::frag frag;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,13 +97,15 @@ __global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
     const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = blockIdx.z * t.TB, n0 = blockIdx.y * BN;
     const T* __restrict__ xp = (const T*)a.x;
 
-    // ---- patch pieces of this thread: global element offset (chunk 0) or -1 for zero fill
+    // ---- patch pieces of this thread: global element offset at chunk 0; padding pieces read
+    // element 0 and are zeroed by `pmask` afterwards (no branch around the loads)
     int gofs[NIT];
+    unsigned pmask = 0;
     const int nitems = a.patch_px * CPP;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int idx = tid + 256 * i;
-        gofs[i] = -1;
+        gofs[i] = 0;
         if (idx < nitems) {
             const int p = idx / CPP, ci = idx % CPP;
             const int tb = fdiv(p, t.div_phw);
@@ -92,41 +113,40 @@ __global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
             const int py = fdiv(r, t.div_pw), px = r - py * t.PW;
             int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
             const int b = b0 + tb;
-            if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix))
+            if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix)) {
                 gofs[i] = b * a.x_img_pitch + iy * a.x_row_pitch + ix * a.Cin + ci * (16 / ES);
+                pmask |= 1u << i;
+            }
         }
     }
     u32x4 pv[NIT];
     auto load_patch = [&](int chunk) {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gofs[i] >= 0) v = *(const u32x4*)(xp + (size_t)gofs[i] + chunk * CK);
-            pv[i] = v;
-        }
+        for (int i = 0; i < NIT; ++i) pv[i] = *(const u32x4*)(xp + (size_t)gofs[i] + chunk * CK);
     };
     auto store_patch = [&](char* buf) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < nitems) *(u32x4*)(buf + (idx / CPP) * PITCH + (idx % CPP) * 16) = pv[i];
+            u32x4 v = pv[i];
+            if (!((pmask >> i) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+            if (idx < nitems) *(u32x4*)(buf + (idx / CPP) * PITCH + (idx % CPP) * 16) = v;
         }
     };
 
     // ---- this lane's pixel columns
     int abase[MI];
+    const int lpx = lane_pixel(l31, a.lane_perm);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        int q = wm * WTM + mi * 32 + l31;
+        int q = wm * WTM + mi * 32 + lpx;
         if (q >= t.npx) q = 0;
         int tb, ty, tx;
         tile_px(t, q, tb, ty, tx);
         abase[mi] = ((tb * t.PH + ty) * t.PW + tx) * PITCH + 8 * h * ES;
     }
 
-    // ---- weight fragment streams (one per 32-row block of this wave), D steps in flight:
-    // the fragments of step s+D are requested as soon as step s has consumed its own, so
-    // an L2 round trip is covered by D steps of MFMA work.
+    // ---- weight fragment streams (one per 32-row block of this wave)
     const int nsteps = a.nchunks * a.T;          // (chunk, tap) steps; two k16 fragments each
     const T* wptr[NI];
 #pragma unroll
@@ -141,8 +161,9 @@ __global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-    frag wr[D][NI][2];
+    frag wr[TU][NI][2];
     auto load_w = [&](int step, frag (&w)[NI][2]) {
+        step = min(step, nsteps - 1);            // the tail re-reads the last step instead of branching
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             w[ni][0] = *(const frag*)(wptr[ni] + (size_t)(step * 2) * FRAG);
@@ -152,19 +173,19 @@ __global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
 
     load_patch(0);
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nsteps) load_w(d, wr[d]);
+    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);
     store_patch(smem);
     __syncthreads();
-    if (a.nchunks > 1) load_patch(1);
+    load_patch(min(1, a.nchunks - 1));
 
-    int chunk = 0, kh = 0, kw = 0, tap = 0;
-    const char* buf = smem;
-    for (int s0 = 0; s0 < nsteps; s0 += D) {
+    const int ngrp = a.T / TU;
+    int step = 0;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const char* buf = smem + (chunk & 1) * a.patch_bytes;
+        for (int grp = 0; grp < ngrp; ++grp) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int s = s0 + d;
-            if (s < nsteps) {
+            for (int j = 0; j < TU; ++j) {
+                const int kh = TU == 9 ? j / 3 : grp, kw = TU == 9 ? j % 3 : j;
                 const int tapoff = (kh * t.PW + kw) * PITCH;
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub) {
@@ -175,24 +196,20 @@ __global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[d][ni][sub], xf[mi]);
+                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[j][ni][sub], xf[mi]);
                 }
-                if (s + D < nsteps) load_w(s + D, wr[d]);
-                if (++kw == a.KW) { kw = 0; ++kh; }
-                if (++tap == a.T) {
-                    // chunk boundary: publish the next patch, fetch the one after it
-                    tap = kh = kw = 0;
-                    ++chunk;
-                    if (chunk < a.nchunks) {
-                        char* nb = smem + (chunk & 1) * a.patch_bytes;
-                        store_patch(nb);
-                        __syncthreads();
-                        buf = nb;
-                        if (chunk + 1 < a.nchunks) load_patch(chunk + 1);
-                    }
-                }
+                load_w(step + TU, wr[j]);
+                ++step;
+                // keep each step's LDS reads and MFMAs together: without this the scheduler hoists
+                // the reads of all TU steps to the top of the body and runs out of registers
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // chunk boundary: publish the next patch (a repeat of the last one at the very end), fetch
+        // the one after it
+        store_patch(smem + ((chunk + 1) & 1) * a.patch_bytes);
+        __syncthreads();
+        load_patch(min(chunk + 2, a.nchunks - 1));
     }
 
     // ---- epilogue: D[row = n][col = pixel]
@@ -201,7 +218,7 @@ __global__ void __launch_bounds__(256) patch_fwd(const PatchFwdArgs a) {
     const T* __restrict__ gatep = (const T*)a.gate;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int q = wm * WTM + mi * 32 + l31;
+        const int q = wm * WTM + mi * 32 + lpx;
         if (q >= t.npx) continue;
         int tb, ty, tx;
         tile_px(t, q, tb, ty, tx);
@@ -335,11 +352,12 @@ template <> struct TrGather<float> {
     }
 };
 
-template <typename T, int WN, int WT, int TPW>
+template <typename T, int WN, int WT, int TPW, int NI>
 __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int BNW = 32 * WN;
+    constexpr int BNW = 32 * WN * NI;
     constexpr int BMP = ES == 2 ? 256 : 128;                  // tile pixels
+    constexpr int NSUB = BMP / 16;                             // 16-pixel MFMA sub-steps per tile
     constexpr int CPP = CK * ES / 16;
     constexpr int PP = CK * ES;                                // patch pixel pitch: 64 B rows are conflict-free for tr reads
     constexpr int GW = BNW * ES;                               // dY row bytes
@@ -347,6 +365,7 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
     constexpr int NIT = 8;                                     // patch pieces per thread (512 / 256 px)
     constexpr int GPR = GW / 16;                               // dY pieces per row
     constexpr int GIT = BMP * GPR / 256;                       // dY pieces per thread
+    constexpr int NA = TrGather<T>::NADDR;
     typedef typename Elem<T>::frag frag;
     static_assert(WN * WT == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -417,11 +436,13 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
         }
     };
 
-    f32x16 acc[TPW];
+    f32x16 acc[NI][TPW];
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][tt][r] = 0.f;
 
     // tap range of this wave; taps past the end are clamped to the last one (their products are
     // computed and dropped) so that the inner loop stays branch-free and the LDS reads of all taps
@@ -441,7 +462,11 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
         tile_px(t, q, tb, ty, tx);
         return Ps + ((tb * t.PH + ty) * t.PW + tx) * PP;
     };
-    const int nsub = (t.npx + 15) / 16;
+    // LDS row addresses of this lane's pixels at tap (0, 0): the same for every tile, so the tile
+    // loop carries no address arithmetic besides one add per tap
+    const char* prow[NSUB][NA];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) TrGather<T>::rows(p_addr, s * 16, lane, prow[s]);
 
     if (tl_beg < tl_end) load_tile(tl_beg);
     for (int tl = tl_beg; tl < tl_end; ++tl) {
@@ -449,17 +474,18 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
         store_tile();
         __syncthreads();
         if (tl + 1 < tl_end) load_tile(tl + 1);
-
-        for (int s = 0; s < nsub; ++s) {
-            const frag gf = TrGather<T>::ld(g_addr, s * 16, wn * 32, lane);
-            // LDS addresses of this lane's pixels at tap (0, 0), shared by every tap
-            const char* prow[TrGather<T>::NADDR];
-            TrGather<T>::rows(p_addr, s * 16, lane, prow);
-            frag xf[TPW];
+        // all NSUB sub-steps run even for a short tile: its missing pixels have zero dY rows
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) xf[tt] = TrGather<T>::ld_rows(prow, toff[tt], lane);
+        for (int s = 0; s < NSUB; ++s) {
+            frag gf[NI], xf[TPW];
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) mma32(acc[tt], gf, xf[tt]);
+            for (int ni = 0; ni < NI; ++ni) gf[ni] = TrGather<T>::ld(g_addr, s * 16, (wn * NI + ni) * 32, lane);
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) xf[tt] = TrGather<T>::ld_rows(prow[s], toff[tt], lane);
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma32(acc[ni][tt], gf[ni], xf[tt]);
         }
     }
 
@@ -471,10 +497,12 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
         if (tap >= a.T) continue;
         const int k = tap * a.Cin + chunk * CK + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(size_t)n * a.k_ld + k] = acc[tt][r];
-        }
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * NI + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)n * a.k_ld + k] = acc[ni][tt][r];
+            }
     }
 }
 
@@ -490,7 +518,7 @@ void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x)
 bool patch_eligible(const cvg_conv_desc* d) {
     if (d->stride != 1 || d->tstep_y != 1 || d->tstep_x != 1) return false;
     if (d->Cin % CK != 0 || d->x_pix_pitch != d->Cin) return false;
-    if (d->ntaps <= 1 || d->ntaps % d->KW != 0) return false;
+    if (!((d->KW == 3 && d->ntaps == 9) || (d->KW == 7 && d->ntaps == 49))) return false;   // instantiated kernels
     if ((int64_t)d->B * d->x_img_pitch >= (1ll << 31)) return false;
     return true;
 }
@@ -525,20 +553,25 @@ int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
-template <typename T, int WM, int WN, int MI, int NI>
-int launch_patch_fwd(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
-    if (set_lds(patch_fwd<T, WM, WN, MI, NI>, p.lds_bytes)) return -1;
+template <typename T, int WM, int WN, int MI, int NI, int KWT>
+int launch_patch_fwd2(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
+    if (set_lds(patch_fwd<T, WM, WN, MI, NI, KWT>, p.lds_bytes)) return -1;
     dim3 grid(p.tiles_y * p.tiles_x, ceil_div(a.N, WN * NI * 32), p.groups);
-    patch_fwd<T, WM, WN, MI, NI><<<grid, 256, p.lds_bytes, s>>>(a);
+    patch_fwd<T, WM, WN, MI, NI, KWT><<<grid, 256, p.lds_bytes, s>>>(a);
     CVG_LAUNCH_CHECK();
     return 0;
 }
+template <typename T, int WM, int WN, int MI, int NI>
+int launch_patch_fwd(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
+    if (p.KW == 3) return launch_patch_fwd2<T, WM, WN, MI, NI, 3>(p, a, s);
+    return launch_patch_fwd2<T, WM, WN, MI, NI, 7>(p, a, s);
+}
 
-template <typename T, int WN, int WT, int TPW>
+template <typename T, int WN, int WT, int TPW, int NI>
 int launch_patch_wgrad(const PatchWgradPlan& p, const PatchWgradArgs& a, hipStream_t s) {
-    if (set_lds(patch_wgrad<T, WN, WT, TPW>, p.lds_bytes)) return -1;
+    if (set_lds(patch_wgrad<T, WN, WT, TPW, NI>, p.lds_bytes)) return -1;
     dim3 grid(p.nchunks, p.n_tiles, p.nsplit);
-    patch_wgrad<T, WN, WT, TPW><<<grid, 256, p.lds_bytes, s>>>(a);
+    patch_wgrad<T, WN, WT, TPW, NI><<<grid, 256, p.lds_bytes, s>>>(a);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -578,6 +611,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
     a.nchunks = p.nchunks; a.patch_px = p.patch_px;
     a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
+    a.lane_perm = (p.TW % 16 == 0) ? 1 : 0;
     fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
     // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
@@ -608,12 +642,15 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     if (!patch_eligible(d)) return;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
-    if (d->N > 64) { p.WN = 4; p.WT = 1; }
+    // waves: WN over 32*NI-channel blocks x WT over tap groups.  Wide layers give every wave two
+    // channel blocks, so each patch fragment read from LDS feeds two MFMAs.
+    int ni = 1;
+    if (d->N > 64) { p.WN = 2; p.WT = 2; ni = 2; }
     else if (d->N > 32) { p.WN = 2; p.WT = 2; }
     else { p.WN = 1; p.WT = 4; }
-    p.BNW = 32 * p.WN;
+    p.BNW = 32 * p.WN * ni;
     const int tpw = ceil_div(p.T, p.WT);
-    if (!(tpw == 9 || tpw == 5 || tpw == 3 || tpw == 13)) return;       // instantiated tap counts
+    if (!(tpw == 5 || tpw == 3 || tpw == 13)) return;                    // instantiated tap counts
     const int bmp = es == 2 ? 256 : 128;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, bmp, 2 * bmp, p.TB, p.TH, p.TW)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
@@ -652,16 +689,16 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     const int tpw = ceil_div(p.T, p.WT);
     int rc = -1;
     if (d->dtype == CVG_BF16) {
-        if (p.WN == 4 && tpw == 9) rc = launch_patch_wgrad<bf16, 4, 1, 9>(p, a, s);
-        else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5>(p, a, s);
-        else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<bf16, 1, 4, 3>(p, a, s);
-        else if (p.WN == 1 && tpw == 13) rc = launch_patch_wgrad<bf16, 1, 4, 13>(p, a, s);
+        if (p.BNW == 128 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5, 2>(p, a, s);
+        else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5, 1>(p, a, s);
+        else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<bf16, 1, 4, 3, 1>(p, a, s);
+        else if (p.WN == 1 && tpw == 13) rc = launch_patch_wgrad<bf16, 1, 4, 13, 1>(p, a, s);
         else CVG_FAIL("patch_wgrad: no kernel for WN %d taps/wave %d", p.WN, tpw);
     } else {
-        if (p.WN == 4 && tpw == 9) rc = launch_patch_wgrad<float, 4, 1, 9>(p, a, s);
-        else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<float, 2, 2, 5>(p, a, s);
-        else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<float, 1, 4, 3>(p, a, s);
-        else if (p.WN == 1 && tpw == 13) rc = launch_patch_wgrad<float, 1, 4, 13>(p, a, s);
+        if (p.BNW == 128 && tpw == 5) rc = launch_patch_wgrad<float, 2, 2, 5, 2>(p, a, s);
+        else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<float, 2, 2, 5, 1>(p, a, s);
+        else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<float, 1, 4, 3, 1>(p, a, s);
+        else if (p.WN == 1 && tpw == 13) rc = launch_patch_wgrad<float, 1, 4, 13, 1>(p, a, s);
         else CVG_FAIL("patch_wgrad: no kernel for WN %d taps/wave %d", p.WN, tpw);
     }
     if (rc) return rc;
