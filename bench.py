@@ -82,12 +82,11 @@ class KernelTimer:
 
     @staticmethod
     def kernel_name(g, kind):
-        n = g.desc.N
+        import ctypes
+        from cvae_gan_amd._lib import lib
         if kind == "fwd":
-            tile = "128x128" if n > 64 else ("256x64" if n > 32 else "256x32")
-            return "igemm_fwd<%s>" % tile
-        tile = "128x128" if n > 64 else ("64x128" if n > 32 else "32x128")
-        return "igemm_wgrad<%s>(+reduce)" % tile
+            return lib.cvg_conv_fwd_kernel(ctypes.byref(g.desc)).decode()
+        return lib.cvg_conv_wgrad_kernel(ctypes.byref(g.desc)).decode() + "(+reduce)"
 
     def per_layer(self, reps):
         """One line per GEMM launch site: layer, kind, GEMM shape, time, algorithmic TFLOP/s."""

@@ -45,6 +45,8 @@ def _load():
         "cvg_conv_fwd_workspace": (sz, [P(ConvDesc)]),
         "cvg_conv_fwd": (C.c_int, [P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "cvg_conv_wgrad_workspace": (sz, [P(ConvDesc)]),
+        "cvg_conv_fwd_kernel": (C.c_char_p, [P(ConvDesc)]),
+        "cvg_conv_wgrad_kernel": (C.c_char_p, [P(ConvDesc)]),
         "cvg_conv_wgrad": (C.c_int, [P(ConvDesc), vp, vp, i32, P(WMap), vp, i32, vp, sz, vp]),
         "cvg_weight_pack": (C.c_int, [P(ConvDesc), P(WMap), vp, vp, vp]),
         "cvg_label_bias": (C.c_int, [vp, vp, i32, i32, vp]),

@@ -11,6 +11,7 @@
 //   patch_wgrad  P[n][tap][c] = sum_pix dY[pix][n] * X[pix+tap][c]
 //                both operands are read from LDS with transposing reads; the dY
 //                fragment is reused across all taps
+#include <stdlib.h>
 #include "conv_patch.h"
 #include "gemm_util.h"
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ int lane_pixel(int l31, int permute) {
 // forward
 // ======================================================================================
 template <typename T, int WM, int WN, int MI, int NI, int KWT>
-__global__ void __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) patch_fwd(const PatchFwdArgs a) {
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patch_fwd(const PatchFwdArgs a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int CPP = CK * ES / 16;            // 16-byte pieces per patch pixel
     constexpr int PITCH = CK * ES + 16;          // conflict-free ds_read_b128 across pixels
@@ -183,21 +184,36 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) patch_fwd(const P
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const char* buf = smem + (chunk & 1) * a.patch_bytes;
         for (int grp = 0; grp < ngrp; ++grp) {
-#pragma unroll
-            for (int j = 0; j < TU; ++j) {
+            // PIPE (one wave per SIMD, registers to spare): the LDS reads of step j+1 are issued
+            // before the MFMAs of step j, so the matrix pipe never waits for LDS inside a group.
+            constexpr bool PIPE = NI >= 2;
+            frag xf[2][2][MI];
+            auto read_x = [&](int j, frag (&x)[2][MI]) {
                 const int kh = TU == 9 ? j / 3 : grp, kw = TU == 9 ? j % 3 : j;
                 const int tapoff = (kh * t.PW + kw) * PITCH;
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    frag xf[MI];
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        xf[mi] = *(const frag*)(buf + abase[mi] + tapoff + sub * 16 * ES);
+                        x[sub][mi] = *(const frag*)(buf + abase[mi] + tapoff + sub * 16 * ES);
+            };
+            if (PIPE) read_x(0, xf[0]);
+#pragma unroll
+            for (int j = 0; j < TU; ++j) {
+                if (PIPE) {
+                    if (j + 1 < TU) read_x(j + 1, xf[(j + 1) & 1]);
+                } else {
+                    // all LDS reads of the step go out back to back into their own registers, then
+                    // the MFMAs run: one LDS round trip per step, hidden by the SIMD's other wave
+                    read_x(j, xf[j & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[j][ni][sub], xf[mi]);
-                }
+                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[j][ni][sub], xf[j & 1][sub][mi]);
                 load_w(step + TU, wr[j]);
                 ++step;
                 // keep each step's LDS reads and MFMAs together: without this the scheduler hoists
@@ -585,6 +601,8 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
     p.BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
     p.BM = d->N > 64 ? 128 : 256;
+    static const char* wide = getenv("CVG_PATCH_WIDE");            // experiment: 256 px x 128 ch tiles (bf16)
+    if (wide && wide[0] == '1' && d->N > 64 && d->dtype == CVG_BF16) p.BM = 256;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, 512, p.TB, p.TH, p.TW)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
     p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
@@ -595,6 +613,8 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     if (eff < 0.5 || p.groups > 65535) return;
     const int patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
     p.lds_bytes = 2 * (size_t)patch_bytes;
+    static const char* extra = getenv("CVG_PATCH_LDS_EXTRA");      // occupancy experiments
+    if (extra) p.lds_bytes += (size_t)atoi(extra);
     p.ok = 1;
 }
 
@@ -616,6 +636,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
     if (d->dtype == CVG_BF16) {
+        if (p.BN == 128 && p.BM == 256) return launch_patch_fwd<bf16, 2, 2, 4, 2>(p, a, s);
         if (p.BN == 128) return launch_patch_fwd<bf16, 1, 4, 4, 1>(p, a, s);
         if (p.BN == 64) return launch_patch_fwd<bf16, 2, 2, 4, 1>(p, a, s);
         return launch_patch_fwd<bf16, 4, 1, 2, 1>(p, a, s);
@@ -661,7 +682,9 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     p.n_tiles = ceil_div(d->N, p.BNW);
     const double eff = (double)d->B * d->OH * d->OW / ((double)p.ntiles * bmp);
     if (eff < 0.5) return;
-    int want = ceil_div(512, p.nchunks * p.n_tiles);
+    // one workgroup per CU fits (accumulators take the whole register file): aim for ~256 of them,
+    // which also halves the partial-slab traffic of the reduce pass compared with two rounds
+    int want = ceil_div(256, p.nchunks * p.n_tiles);
     if (want > p.ntiles) want = p.ntiles;
     if (want < 1) want = 1;
     p.tiles_per_split = ceil_div(p.ntiles, want);

@@ -544,6 +544,24 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     return d->dtype == CVG_BF16 ? launch_fwd<bf16>(d, a, s) : launch_fwd<float>(d, a, s);
 }
 
+const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {
+    if (patch_enabled()) {
+        PatchPlan pp;
+        patch_fwd_plan(d, pp);
+        if (pp.ok) return pp.BN == 128 ? "patch_fwd<128px x 128ch>" : (pp.BN == 64 ? "patch_fwd<256px x 64ch>" : "patch_fwd<256px x 32ch>");
+    }
+    return d->N > 64 ? "igemm_fwd<128x128>" : (d->N > 32 ? "igemm_fwd<256x64>" : "igemm_fwd<256x32>");
+}
+
+const char* cvg_conv_wgrad_kernel(const cvg_conv_desc* d) {
+    if (patch_enabled()) {
+        PatchWgradPlan wp;
+        patch_wgrad_plan(d, wp);
+        if (wp.ok) return wp.BNW == 128 ? "patch_wgrad<128ch>" : (wp.BNW == 64 ? "patch_wgrad<64ch>" : "patch_wgrad<32ch>");
+    }
+    return d->N > 64 ? "igemm_wgrad<128x128>" : (d->N > 32 ? "igemm_wgrad<64x128>" : "igemm_wgrad<32x128>");
+}
+
 size_t cvg_conv_wgrad_workspace(const cvg_conv_desc* d) {
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
     WgradPlan p = plan_wgrad(d, (int)M);

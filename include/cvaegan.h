@@ -97,6 +97,9 @@ typedef struct cvg_wmap {
 } cvg_wmap;
 
 size_t cvg_conv_wgrad_workspace(const cvg_conv_desc* d);
+/* Name of the kernel family the library picks for this descriptor (profiling labels).     */
+const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d);
+const char* cvg_conv_wgrad_kernel(const cvg_conv_desc* d);
 int    cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_t dy_ld,
                       const cvg_wmap* map, float* grad, int32_t accumulate,
                       void* ws, size_t ws_bytes, cvg_stream s);
