@@ -28,7 +28,7 @@ struct TileGeom {
 struct PatchFwdArgs {
     const void* x; const void* wf; void* y;
     const float* bias; const float* cbias; const int* labels; const void* res; const void* gate;
-    int B, H, W, Cin, x_img_pitch, x_row_pitch;
+    int B, H, W, Cin, x_img_pitch, x_row_pitch, x_pix_pitch;
     int off_y, off_x, pad_mode, KW, T;
     int OH, OW, N;
     int y_img_pitch, y_row_pitch, y_pix_pitch, oy_mul, oy_off, ox_mul, ox_off;
@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
     // one tap row of a 7x7 kernel.  The body is branch-free and every load in it is
     // unconditional, so the compiler can count outstanding loads exactly and a step only waits
     // for its own fragments (issued TU steps, i.e. > 2000 cycles of MFMA work, earlier).
-    constexpr int TU = (KWT == 3 && sizeof(T) == 2) ? 9 : KWT;   // f32 fragments are twice as wide: one tap row
+    // KWT: 3 = 3x3, 7 = 7x7, 1 = 7x1 (seven vertical taps; the stem and the tail's input gradient,
+    // whose 8-pixel x 4-channel windows play the part of 32 "channels")
+    constexpr int TU = KWT == 1 ? 7 : ((KWT == 3 && sizeof(T) == 2) ? 9 : KWT);   // f32 fragments are twice as wide: one tap row
     typedef typename Elem<T>::frag frag;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
             int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
             const int b = b0 + tb;
             if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix)) {
-                gofs[i] = b * a.x_img_pitch + iy * a.x_row_pitch + ix * a.Cin + ci * (16 / ES);
+                gofs[i] = b * a.x_img_pitch + iy * a.x_row_pitch + ix * a.x_pix_pitch + ci * (16 / ES);
                 pmask |= 1u << i;
             }
         }
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
             constexpr bool PIPE = NI >= 2;
             frag xf[2][2][MI];
             auto read_x = [&](int j, frag (&x)[2][MI]) {
-                const int kh = TU == 9 ? j / 3 : grp, kw = TU == 9 ? j % 3 : j;
+                const int kh = KWT == 1 ? j : (TU == 9 ? j / 3 : grp), kw = KWT == 1 ? 0 : (TU == 9 ? j % 3 : j);
                 const int tapoff = (kh * t.PW + kw) * PITCH;
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -301,7 +303,7 @@ __global__ void patch_pack(const float* __restrict__ canonical, T* __restrict__ 
 // ======================================================================================
 struct PatchWgradArgs {
     const void* x; const void* dy; float* ws;
-    int B, H, W, Cin, x_img_pitch, x_row_pitch;
+    int B, H, W, Cin, x_img_pitch, x_row_pitch, x_pix_pitch;
     int off_y, off_x, pad_mode, KW, T;
     int OH, OW, dy_ld, dy_cols;
     int patch_px, ntiles, tiles_per_split, tiles_per_group;
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
                 int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
                 const int b = b0 + tb;
                 if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix))
-                    v = *(const u32x4*)(xp + ((size_t)b * a.x_img_pitch + (size_t)(iy * a.x_row_pitch + ix * a.Cin) +
+                    v = *(const u32x4*)(xp + ((size_t)b * a.x_img_pitch + (size_t)(iy * a.x_row_pitch + ix * a.x_pix_pitch) +
                                               chunk * CK + ci * (16 / ES)));
             }
             pv[i] = v;
@@ -533,8 +535,10 @@ void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x)
 
 bool patch_eligible(const cvg_conv_desc* d) {
     if (d->stride != 1 || d->tstep_y != 1 || d->tstep_x != 1) return false;
-    if (d->Cin % CK != 0 || d->x_pix_pitch != d->Cin) return false;
-    if (!((d->KW == 3 && d->ntaps == 9) || (d->KW == 7 && d->ntaps == 49))) return false;   // instantiated kernels
+    if (d->Cin % CK != 0) return false;
+    if (d->x_pix_pitch != d->Cin && !(d->Cin == CK && d->pad_mode == CVG_PAD_ZERO)) return false;   // overlapping windows: one chunk
+    if (!((d->KW == 3 && d->ntaps == 9) || (d->KW == 7 && d->ntaps == 49) || (d->KW == 1 && d->ntaps == 7)))
+        return false;                                                                        // instantiated kernels
     if ((int64_t)d->B * d->x_img_pitch >= (1ll << 31)) return false;
     return true;
 }
@@ -580,6 +584,7 @@ int launch_patch_fwd2(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) 
 template <typename T, int WM, int WN, int MI, int NI>
 int launch_patch_fwd(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
     if (p.KW == 3) return launch_patch_fwd2<T, WM, WN, MI, NI, 3>(p, a, s);
+    if (p.KW == 1) return launch_patch_fwd2<T, WM, WN, MI, NI, 1>(p, a, s);
     return launch_patch_fwd2<T, WM, WN, MI, NI, 7>(p, a, s);
 }
 
@@ -624,7 +629,9 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     PatchFwdArgs a;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels; a.res = res; a.gate = gate;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch; a.x_pix_pitch = d->x_pix_pitch;
+    // overlapping windows (pixel pitch < Cin): the last whole window starts Cin/pitch - 1 pixels before the row end
+    if (d->x_pix_pitch != d->Cin) a.W = d->W - d->Cin / d->x_pix_pitch + 1;
     a.off_y = d->off_y; a.off_x = d->off_x; a.pad_mode = d->pad_mode; a.KW = p.KW; a.T = p.T;
     a.OH = d->OH; a.OW = d->OW; a.N = d->N;
     a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
@@ -670,8 +677,8 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     else if (d->N > 32) { p.WN = 2; p.WT = 2; }
     else { p.WN = 1; p.WT = 4; }
     p.BNW = 32 * p.WN * ni;
-    const int tpw = ceil_div(p.T, p.WT);
-    if (!(tpw == 5 || tpw == 3 || tpw == 13)) return;                    // instantiated tap counts
+    const int tpw = p.T == 7 ? (p.WN == 1 ? 3 : 5) : ceil_div(p.T, p.WT);   // 7 taps ride the 3- / 5-tap kernels
+    if (!(tpw == 5 || tpw == 3 || tpw == 13)) return;                        // instantiated tap counts
     const int bmp = es == 2 ? 256 : 128;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, bmp, 2 * bmp, p.TB, p.TH, p.TW)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
@@ -701,7 +708,9 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
                        const cvg_wmap* map, float* grad, int accumulate, float* ws, hipStream_t s) {
     PatchWgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch; a.x_pix_pitch = d->x_pix_pitch;
+    // overlapping windows (pixel pitch < Cin): the last whole window starts Cin/pitch - 1 pixels before the row end
+    if (d->x_pix_pitch != d->Cin) a.W = d->W - d->Cin / d->x_pix_pitch + 1;
     a.off_y = d->off_y; a.off_x = d->off_x; a.pad_mode = d->pad_mode; a.KW = p.KW; a.T = p.T;
     a.OH = d->OH; a.OW = d->OW; a.dy_ld = dy_ld; a.dy_cols = dy_ld;
     a.patch_px = p.patch_px; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
@@ -709,7 +718,7 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     a.n_rows = p.n_tiles * p.BNW; a.k_ld = p.T * d->Cin;
     fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
     a.div_tpg = make_fastdiv(a.tiles_per_group);
-    const int tpw = ceil_div(p.T, p.WT);
+    const int tpw = p.T == 7 ? (p.WN == 1 ? 3 : 5) : ceil_div(p.T, p.WT);
     int rc = -1;
     if (d->dtype == CVG_BF16) {
         if (p.BNW == 128 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5, 2>(p, a, s);
