@@ -524,8 +524,8 @@ __global__ void tanh_fwd(const T* __restrict__ pre, float* __restrict__ dec, int
     for (int c = 0; c < 3; ++c) dec[((size_t)b * 3 + c) * PP + hw] = tanhf(v[c]);
 }
 template <typename T>
-__global__ void tanh_bwd(const float* __restrict__ d_dec, const float* __restrict__ dec, T* __restrict__ dpre, int B,
-                         int PP) {
+__global__ void tanh_bwd(const float* __restrict__ d_dec, const float* __restrict__ dec, T* __restrict__ dpre,
+                         T* __restrict__ win, int B, int PP, int P) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * PP) return;
     const int b = (int)(i / PP), hw = (int)(i % PP);
@@ -539,6 +539,11 @@ __global__ void tanh_bwd(const float* __restrict__ d_dec, const float* __restric
         v[c] = d_dec[o] * (1.f - t * t);
     }
     store8<T>(dpre + (size_t)i * 8, v);
+    if (win) {
+        const int y = hw / P, x = hw - y * P;
+        const float v4[4] = {v[0], v[1], v[2], 0.f};
+        store4<T>(win + (((size_t)b * (P + 12) + y + 6) * (P + 14) + x + 6) * 4, v4);
+    }
 }
 
 __global__ void __launch_bounds__(256) mse_partial(const float* __restrict__ dec, const float* __restrict__ x,
@@ -831,10 +836,11 @@ int cvg_tanh_fwd(const void* pre, float* dec, int32_t dtype, int32_t B, int32_t 
     CVG_LAUNCH_CHECK();
     return 0;
 }
-int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, int32_t dtype, int32_t B, int32_t P,
+int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, void* dpre_win, int32_t dtype, int32_t B, int32_t P,
                  cvg_stream stream) {
     CVG_CHECK(d_dec && dec && dpre && B > 0 && P > 0, "tanh_bwd: bad args");
-    DISPATCH(dtype, tanh_bwd<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>(d_dec, dec, (T*)dpre, B, P * P));
+    DISPATCH(dtype, tanh_bwd<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>(d_dec, dec, (T*)dpre,
+                                                                                           (T*)dpre_win, B, P * P, P));
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -444,8 +444,13 @@ class Engine:
         d["tail_key"] = key
         d["tail"] = _Gemm(self, _desc(T, B, P, P, ngf, P, P, 4, 7, 49, off=(-3, -3), pad_mode=PAD_REFLECT),
                           _wmap(1, ngf * 49, 0, ngf, 1, 49, 3, ngf, 49), key + "weight")
-        d["tail_dg"] = _Gemm(self, _desc(T, B, P, P, 8, P + 6, P + 6, ngf, 7, 49, off=(-6, -6)),
-                             _wmap(1, 49, 0, 8, 1, ngf * 49, ngf, 3, 49, tap_mode=1), key + "weight")
+        # input gradient w.r.t. the reflection-padded tensor = full correlation of dpre with the
+        # flipped kernel; dpre sits zero-padded by 6 in a 4-channel image so that, like the
+        # stem, it is 7 row taps of 8-pixel x 4-channel windows
+        table = [((6 - kh) * 7 + (6 - kw)) if kw < 7 else -1 for kh in range(7) for kw in range(8)]
+        d["tail_dg"] = _Gemm(self, _desc(T, B, P + 12, P + 14, 32, P + 6, P + 6, ngf, 1, 7, x_pix=4),
+                             _wmap(1, 49, 0, 4, 1, ngf * 49, ngf, 3, 56, tap_mode=2, table=table), key + "weight")
+        d["dpre_win"] = self._t(B, P + 12, P + 14, 4)
         d["tail_bias"] = self._f(4)
         d["pre"] = self._t(B * P * P, 4)
         d["dpre"] = self._t(B * P * P, 8)
@@ -603,12 +608,12 @@ class Engine:
 
     def dec_backward(self, d_dec, mask=None):
         d, B, P, s, ngf = self.dec, self.B, self.P, self.s, self.ngf
-        ops.tanh_bwd(d_dec, d["dec"], d["dpre"], B, P)
+        ops.tanh_bwd(d_dec, d["dec"], d["dpre"], B, P, d["dpre_win"])
         last = d["ups"][-1]
         self._wgrad(d["tail"], last["y"], d["dpre"], 8)
         ops.colsum(d["dpre"], B * P * P, 8, 8, d["bgrad8"], self.red_ws)
         ops.permute_f32(d["bgrad8"], self.grads[d["tail_key"] + "bias"], 3)
-        self._fwd(d["tail_dg"], d["dpre"], d["dxp"])
+        self._fwd(d["tail_dg"], d["dpre_win"], d["dxp"])
         ops.reflect_fold(d["dxp"], last["d_y"], B, P, P, ngf, 3)
         for i in range(len(d["ups"]) - 1, -1, -1):
             up = d["ups"][i]

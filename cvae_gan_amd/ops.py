@@ -136,8 +136,9 @@ def tanh_fwd(pre, dec, B, P):
     check(lib.cvg_tanh_fwd(ptr(pre), ptr(dec), dt(pre), B, P, stream()))
 
 
-def tanh_bwd(d_dec, dec, dpre, B, P):
-    check(lib.cvg_tanh_bwd(ptr(d_dec), ptr(dec), ptr(dpre), dt(dpre), B, P, stream()))
+def tanh_bwd(d_dec, dec, dpre, B, P, dpre_win=None):
+    check(lib.cvg_tanh_bwd(ptr(d_dec), ptr(dec), ptr(dpre), ptr(dpre_win),
+                           dt(dpre), B, P, stream()))
 
 
 def mse_fwd_bwd(dec, x, d_dec, ll, numel, batch_size, scale, ws):

@@ -201,10 +201,13 @@ int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_
                      int32_t C, int32_t pad, cvg_stream s);
 
 /* nn.Tanh on the tail conv output (networks.py:149): pre [B*P*P][4] (dtype) ->
- * dec NCHW f32 [B][3][P][P]; backward d_dec NCHW f32 -> dpre [B*P*P][8] (dtype).   */
+ * dec NCHW f32 [B][3][P][P]; backward d_dec NCHW f32 -> dpre [B*P*P][8] (dtype).
+ * dpre_win (may be NULL) receives the same gradient as the interior [6..6+P) x [6..6+P)
+ * of a 4-channel image [B][P+12][P+14][4] whose border the caller keeps at zero: the
+ * layout the tail's input-gradient convolution reads as 7 row taps of 8-pixel windows. */
 int cvg_tanh_fwd(const void* pre, float* dec, int32_t dtype, int32_t B, int32_t P, cvg_stream s);
-int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, int32_t dtype, int32_t B,
-                 int32_t P, cvg_stream s);
+int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, void* dpre_win, int32_t dtype,
+                 int32_t B, int32_t P, cvg_stream s);
 /* Reconstruction loss of models/cvae.py:139: ll = 50 * mean((dec - x)^2) / batch_size,
  * and d_dec = scale * 100 * (dec - x) / (numel * batch_size).                       */
 int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, int64_t numel,
