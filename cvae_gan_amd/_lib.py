@@ -26,6 +26,11 @@ class WMap(C.Structure):
         [("tap_table", C.c_int16 * 64)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("map", WMap), ("canonical", C.c_void_p), ("packed", C.c_void_p), ("n_groups", C.c_int64)] + \
+        [(n, C.c_int32) for n in ("block0", "mode", "rows", "ld", "nchunks", "ntaps", "Cin", "dtype")]
+
+
 class CvgError(RuntimeError):
     pass
 
@@ -49,6 +54,8 @@ def _load():
         "cvg_conv_wgrad_kernel": (C.c_char_p, [P(ConvDesc)]),
         "cvg_conv_wgrad": (C.c_int, [P(ConvDesc), vp, vp, i32, P(WMap), vp, i32, vp, sz, vp]),
         "cvg_weight_pack": (C.c_int, [P(ConvDesc), P(WMap), vp, vp, vp]),
+        "cvg_weight_pack_job": (C.c_int, [P(ConvDesc), P(WMap), vp, vp, i32, P(PackJob)]),
+        "cvg_weight_pack_batch": (C.c_int, [vp, i32, i32, vp]),
         "cvg_label_bias": (C.c_int, [vp, vp, i32, i32, vp]),
         "cvg_label_bias_bwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "cvg_pack_image": (C.c_int, [vp, vp, i32, i32, i32, vp]),

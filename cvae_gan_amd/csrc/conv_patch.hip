@@ -230,52 +230,80 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
         load_patch(min(chunk + 2, a.nchunks - 1));
     }
 
-    // ---- epilogue: D[row = n][col = pixel]
-    T* __restrict__ yp = (T*)a.y;
+    // ---- epilogue.  D[row = n][col = pixel]: a lane holds 4 consecutive channels of one pixel, so
+    // direct stores would scatter 8-byte pieces over 32 cache lines per instruction.  The tile goes
+    // through LDS instead (the patch buffers are free: every wave passed the barrier that follows
+    // its last read) and leaves as whole pixel rows, 16 bytes per lane, consecutive lanes on
+    // consecutive addresses.
+    constexpr int OP = BN * ES + 16;             // staged row pitch
     const T* __restrict__ resp = (const T*)a.res;
     const T* __restrict__ gatep = (const T*)a.gate;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int q = wm * WTM + mi * 32 + lpx;
-        if (q >= t.npx) continue;
+        int tb, ty, tx;
+        tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
+        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+        const bool live = q < t.npx && b < a.B && oy < a.OH && ox < a.OW;
+        const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
+                            (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+        const float* cb = (a.cbias && live) ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nl = wn * WTN + ni * 32 + 8 * g4 + 4 * h, n = n0 + nl;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g4 + j];
+                if (live && n < a.N) {
+                    if (a.bias) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
+                    }
+                    if (cb) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
+                    }
+                    if (resp) {
+                        float r[4];
+                        load4<T>(resp + yoff + n, r);
+                        if (gatep) {
+                            float gt[4];
+                            load4<T>(gatep + yoff + n, gt);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += r[j];
+                    }
+                }
+                store4<T>((T*)(smem + (wm * WTM + mi * 32 + lpx) * OP) + nl, v);
+            }
+        }
+    }
+    __syncthreads();
+    T* __restrict__ yp = (T*)a.y;
+    constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
+    constexpr int BMT = WM * WTM;
+    constexpr int EPP = 16 / ES;                 // elements per piece
+#pragma unroll
+    for (int i = 0; i < BMT * PPR / 256; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / PPR, pc = idx % PPR;
+        const int n = n0 + pc * EPP;
+        if (q >= t.npx || n >= a.N) continue;
         int tb, ty, tx;
         tile_px(t, q, tb, ty, tx);
         const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
         if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
         const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
                             (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
-        const float* cb = a.cbias ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int n = n0 + wn * WTN + ni * 32 + 8 * g4 + 4 * h;
-                if (n >= a.N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g4 + j];
-                if (a.bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
-                }
-                if (cb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
-                }
-                if (resp) {
-                    float r[4];
-                    load4<T>(resp + yoff + n, r);
-                    if (gatep) {
-                        float gt[4];
-                        load4<T>(gatep + yoff + n, gt);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += r[j];
-                }
-                store4<T>(yp + yoff + n, v);
-            }
+        const u32x4 v = *(const u32x4*)(smem + q * OP + pc * 16);
+        if (n + EPP <= a.N) {
+            *(u32x4*)(yp + yoff + n) = v;
+        } else {                                 // N is a multiple of 4: half a 16-bit piece
+            *(unsigned long long*)(yp + yoff + n) = ((unsigned long long)v[1] << 32) | v[0];
         }
     }
 }
@@ -618,6 +646,8 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     if (eff < 0.5 || p.groups > 65535) return;
     const int patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
     p.lds_bytes = 2 * (size_t)patch_bytes;
+    const size_t stage_bytes = (size_t)p.BM * (p.BN * es + 16);     // the output tile is staged over the patch buffers
+    if (p.lds_bytes < stage_bytes) p.lds_bytes = stage_bytes;
     static const char* extra = getenv("CVG_PATCH_LDS_EXTRA");      // occupancy experiments
     if (extra) p.lds_bytes += (size_t)atoi(extra);
     p.ok = 1;
@@ -734,7 +764,7 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
         else CVG_FAIL("patch_wgrad: no kernel for WN %d taps/wave %d", p.WN, tpw);
     }
     if (rc) return rc;
-    const int64_t n = (int64_t)map->n_valid * a.k_ld;
+    const int64_t n = (int64_t)map->n_valid * (a.k_ld / 4);
     wgrad_reduce<<<ceil_div(n, 256), 256, 0, s>>>(ws, grad, *map, a.n_rows, a.k_ld, p.nsplit, accumulate);
     CVG_LAUNCH_CHECK();
     return 0;

@@ -76,36 +76,44 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     }
 }
 
-// Partial sums [2][nblk][C] -> per-channel totals.  One 256-thread block per 16 channels:
-// thread (lane = t / 16, ch = t % 16) strides the partial blocks, then the 16 lanes meet in LDS.
-__device__ __forceinline__ void sum_partials(const float* __restrict__ ws, int nblk, int C, int c0, double& s,
+// Partial sums [2][nblk][C] -> per-channel totals.  One wave per channel (4 per block): every lane
+// issues all of its loads (nblk <= 512: at most 8) before the first add, then the 64 lanes meet in
+// a butterfly whose order is fixed, so the totals are run-to-run stable.
+constexpr int FIN_CH = 4;                   // channels per 256-thread block
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void sum_partials(const float* __restrict__ ws, int nblk, int C, int c, double& s,
                                              double& ss, bool want_ss) {
-    __shared__ double red[2][16][16];
-    const int ch = threadIdx.x & 15, ln = threadIdx.x >> 4;
-    const int c = c0 + ch;
+    const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int k = ln; k < nblk; k += 16) {
-            a += ws[(size_t)k * C + c];
-            if (want_ss) b += ws[((size_t)nblk + k) * C + c];
+    if (c < C) {
+        for (int k0 = 0; k0 < nblk; k0 += 512) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + lane + 64 * i;
+                va[i] = k < nblk ? ws[(size_t)k * C + c] : 0.f;
+                vb[i] = (want_ss && k < nblk) ? ws[((size_t)nblk + k) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a += va[i]; b += vb[i]; }
         }
-    red[0][ln][ch] = a;
-    red[1][ln][ch] = b;
-    __syncthreads();
-    s = ss = 0.0;
-    if (ln == 0) {
-        for (int k = 0; k < 16; ++k) { s += red[0][k][ch]; ss += red[1][k][ch]; }
     }
+    s = wave_sum_d(a);
+    ss = wave_sum_d(b);
 }
 
 __global__ void __launch_bounds__(256) stats_finalize(const float* __restrict__ ws, int nblk, int M, int C,
                                                       float* __restrict__ stats, float* running_mean,
                                                       float* running_var, long long* nbt) {
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     double s, ss;
-    sum_partials(ws, nblk, C, blockIdx.x * 16, s, ss, true);
+    sum_partials(ws, nblk, C, c, s, ss, true);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    if ((threadIdx.x >> 4) != 0 || c >= C) return;
+    if ((threadIdx.x & 63) != 0 || c >= C) return;
     const double mean = s / M;
     double var = ss / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -128,10 +136,10 @@ __global__ void eval_stats(const float* rm, const float* rv, int C, float* stats
 // sums partials; out0[map(c)] = sum of partial 0, out1[c] = sum of partial 1 (optional)
 __global__ void __launch_bounds__(256) sum_finalize(const float* __restrict__ ws, int nblk, int C, float* out0,
                                                     float* out1, int md, int ma, int mb) {
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     double s, t;
-    sum_partials(ws, nblk, C, blockIdx.x * 16, s, t, out1 != nullptr);
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    if ((threadIdx.x >> 4) != 0 || c >= C) return;
+    sum_partials(ws, nblk, C, c, s, t, out1 != nullptr);
+    if ((threadIdx.x & 63) != 0 || c >= C) return;
     out0[(c / md) * ma + (c % md) * mb] = (float)s;
     if (out1) out1[c] = (float)t;
 }
@@ -286,20 +294,49 @@ __global__ void __launch_bounds__(256) per_image_colsum(const T* __restrict__ dy
         S[(size_t)blockIdx.x * C + col] = t;
     }
 }
-__global__ void label_bias_scatter(const float* __restrict__ S, const int* __restrict__ labels, int B, int cout,
-                                   int y_dim, float* __restrict__ dw, float* __restrict__ dbias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over (y_dim + 1) * cout
-    if (i >= (y_dim + 1) * cout) return;
-    const int n = i % cout, c = i / cout;
-    float s = 0.f;
-    if (c == y_dim) {
-        for (int b = 0; b < B; ++b) s += S[(size_t)b * cout + n];
-        if (dbias) dbias[n] = s;
+// Blocks [0, y_dim): one class each; its images are listed in batch order in LDS, then thread n sums
+// S[b][n] over the list.  Blocks from y_dim on: the plain bias gradient, FIN_CH channels per block,
+// summed over all images like any other set of partials.
+__global__ void __launch_bounds__(256) label_bias_scatter(const float* __restrict__ S, const int* __restrict__ labels,
+                                                          int B, int cout, int y_dim, float* __restrict__ dw,
+                                                          float* __restrict__ dbias) {
+    if ((int)blockIdx.x >= y_dim) {
+        const int n = (blockIdx.x - y_dim) * FIN_CH + (threadIdx.x >> 6);
+        double s, unused;
+        sum_partials(S, B, cout, n, s, unused, false);
+        if ((threadIdx.x & 63) == 0 && n < cout && dbias) dbias[n] = (float)s;
         return;
     }
-    for (int b = 0; b < B; ++b) if (labels[b] == c) s += S[(size_t)b * cout + n];
-    float* p = dw + ((size_t)n * (3 + y_dim) + 3 + c) * 49;
-    for (int t = 0; t < 49; ++t) p[t] = s;
+    __shared__ int list[256];
+    __shared__ int wcount[4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};                       // cout <= 1024
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const bool hit = b < B && labels[b] == c;
+        const unsigned long long m = __ballot(hit);
+        __syncthreads();                                     // the previous list has been consumed
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) base += wcount[w]; total += wcount[w]; }
+        if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = threadIdx.x + 256 * q;
+            if (n >= cout) continue;
+            for (int i = 0; i < total; ++i) s[q] += S[(size_t)list[i] * cout + n];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = threadIdx.x + 256 * q;
+        if (n >= cout) continue;
+        float* p = dw + ((size_t)n * (3 + y_dim) + 3 + c) * 49;
+        for (int t = 0; t < 49; ++t) p[t] = s[q];
+    }
 }
 
 // ---- reparameterisation + KL -----------------------------------------------------------------
@@ -561,12 +598,14 @@ __global__ void __launch_bounds__(256) mse_partial(const float* __restrict__ dec
     __syncthreads();
     if (threadIdx.x == 0) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void mse_finalize(const float* ws, int nblk, float* ll, float scale) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += ws[b];
-        *ll = (float)(s * scale);
-    }
+__global__ void __launch_bounds__(256) mse_finalize(const float* ws, int nblk, float* ll, float scale) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) a += ws[b];
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) *ll = (float)((red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
 // ---- AdamW ------------------------------------------------------------------------------------------
@@ -678,7 +717,7 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
     DISPATCH(dtype, colreduce<T, RED_STATS><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    stats_finalize<<<grid1(C, 16), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
+    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -712,7 +751,7 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
     RedArgs a = {x, dy, y, stats, ws, M, C, C, red_blocks(M, C), C};
     DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    sum_finalize<<<grid1(C, 16), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
+    sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
     CVG_LAUNCH_CHECK();
     const int RL = 256 / (C / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
@@ -732,7 +771,7 @@ int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, f
     RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
     DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, C / Cb), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    sum_finalize<<<grid1(C, 16), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
+    sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -758,7 +797,7 @@ int cvg_label_bias_bwd(const void* dy, int32_t dtype, const int32_t* labels, int
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype, per_image_colsum<T><<<B, red_threads(cout), 0, s>>>((const T*)dy, ws, pixels, cout));
     CVG_LAUNCH_CHECK();
-    label_bias_scatter<<<grid1((int64_t)(y_dim + 1) * cout), 256, 0, s>>>(ws, labels, B, cout, y_dim, dw, dbias);
+    label_bias_scatter<<<y_dim + grid1(cout, FIN_CH), 256, 0, s>>>(ws, labels, B, cout, y_dim, dw, dbias);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -853,7 +892,7 @@ int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, i
     const float coef = scale * 100.f / ((float)numel * batch_size);
     mse_partial<<<nb, 256, 0, s>>>(dec, x, d_dec, ws, numel, coef);
     CVG_LAUNCH_CHECK();
-    mse_finalize<<<1, 64, 0, s>>>(ws, nb, ll, 50.f / ((float)numel * batch_size));
+    mse_finalize<<<1, 256, 0, s>>>(ws, nb, ll, 50.f / ((float)numel * batch_size));
     CVG_LAUNCH_CHECK();
     return 0;
 }

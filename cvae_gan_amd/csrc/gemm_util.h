@@ -47,18 +47,39 @@ __device__ __forceinline__ int wmap_index(const cvg_wmap& m, int n, int k) {
 }
 
 
-// partial slabs [nsplit][n_rows][k_ld] -> canonical gradient (fixed summation order)
-static __global__ void wgrad_reduce(const float* __restrict__ ws, float* __restrict__ grad, const cvg_wmap map,
-                             int n_rows, int k_ld, int nsplit, int accumulate) {
+// partial slabs [nsplit][n_rows][k_ld] -> canonical gradient (fixed summation order).  One thread
+// per 4 consecutive k (k_ld is a multiple of 4): 16-byte slab reads, four slabs in flight.
+static __global__ void __launch_bounds__(256) wgrad_reduce(const float* __restrict__ ws, float* __restrict__ grad,
+                                                           const cvg_wmap map, int n_rows, int k_ld, int nsplit,
+                                                           int accumulate) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)map.n_valid * k_ld) return;
-    const int n = (int)(idx / k_ld), k = (int)(idx % k_ld);
-    const int ci = wmap_index(map, n, k);
-    if (ci < 0) return;
-    float s = 0.f;
+    const int k4 = k_ld >> 2;
+    if (idx >= (int64_t)map.n_valid * k4) return;
+    const int n = (int)(idx / k4), k = (int)(idx % k4) * 4;
+    int ci[4];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ci[e] = wmap_index(map, n, k + e); any |= ci[e] >= 0; }
+    if (!any) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     const size_t stride = (size_t)n_rows * k_ld;
     const float* p = ws + (size_t)n * k_ld + k;
-    for (int z = 0; z < nsplit; ++z) s += p[z * stride];
-    grad[ci] = accumulate ? grad[ci] + s : s;
+    int z = 0;
+    for (; z + 4 <= nsplit; z += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p + (size_t)(z + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+    }
+    for (; z < nsplit; ++z) {
+        const f32x4 v = *(const f32x4*)(p + (size_t)z * stride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (ci[e] >= 0) grad[ci[e]] = accumulate ? grad[ci[e]] + s[e] : s[e];
 }
-

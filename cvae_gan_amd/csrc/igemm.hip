@@ -386,6 +386,44 @@ __global__ void weight_pack(const float* __restrict__ canonical, T* __restrict__
     packed[idx] = from_f32<T>(ci >= 0 ? canonical[ci] : 0.f);
 }
 
+// every layout of a network in one launch: block -> job by bisection over block0, 8 elements per thread
+template <typename T>
+__device__ __forceinline__ void pack_group(const cvg_pack_job& j, int64_t g) {
+    int n, k;
+    if (j.mode == 1) {                       // fragment order, see patch_pack
+        const int lane = (int)(g & 63);
+        const int64_t f = g >> 6;
+        const int nk = j.nchunks * j.ntaps * 2;
+        const int kstep = (int)(f % nk), nblk = (int)(f / nk);
+        n = nblk * 32 + (lane & 31);
+        const int chunk = kstep / (2 * j.ntaps), tap = (kstep >> 1) % j.ntaps, sub = kstep & 1;
+        k = tap * j.Cin + chunk * 32 + sub * 16 + 8 * (lane >> 5);
+    } else {
+        const int64_t idx = g * 8;
+        n = (int)(idx / j.ld);
+        k = (int)(idx % j.ld);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = wmap_index(j.map, n, k + e);
+        v[e] = ci >= 0 ? j.canonical[ci] : 0.f;
+    }
+    store8<T>((T*)j.packed + g * 8, v);
+}
+__global__ void __launch_bounds__(256) weight_pack_batch(const cvg_pack_job* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const cvg_pack_job& j = jobs[lo];
+    const int64_t g = (int64_t)(blockIdx.x - j.block0) * 256 + threadIdx.x;
+    if (g >= j.n_groups) return;
+    if (j.dtype == CVG_BF16) pack_group<bf16>(j, g);
+    else pack_group<float>(j, g);
+}
+
 // ---- host side -------------------------------------------------------------------
 int elem_size(int dtype) { return dtype == CVG_BF16 ? 2 : 4; }
 
@@ -595,7 +633,7 @@ int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_
     hipStream_t s = (hipStream_t)stream;
     int rc = d->dtype == CVG_BF16 ? launch_wgrad<bf16>(p, a, s) : launch_wgrad<float>(p, a, s);
     if (rc) return rc;
-    const int64_t n = (int64_t)map->n_valid * p.k_ld;
+    const int64_t n = (int64_t)map->n_valid * (p.k_ld / 4);
     wgrad_reduce<<<ceil_div(n, 256), 256, 0, s>>>(a.ws, grad, *map, p.n_rows, p.k_ld, p.nsplit, accumulate);
     CVG_LAUNCH_CHECK();
     return 0;
@@ -615,6 +653,37 @@ int cvg_weight_pack(const cvg_conv_desc* d, const cvg_wmap* map, const float* ca
     const int64_t n = (int64_t)rows * ld;
     if (d->dtype == CVG_BF16) weight_pack<bf16><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (bf16*)packed, *map, rows, ld);
     else weight_pack<float><<<ceil_div(n, 256), 256, 0, s>>>(canonical, (float*)packed, *map, rows, ld);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_weight_pack_job(const cvg_conv_desc* d, const cvg_wmap* map, const float* canonical, void* packed,
+                        int32_t block0, cvg_pack_job* job) {
+    CVG_CHECK(d && map && canonical && packed && job && d->w_rows > 0 && d->w_ld > 0, "weight_pack_job: bad args");
+    CVG_CHECK(map->kd > 0 && map->nd > 0, "weight_pack_job: bad map");
+    job->map = *map; job->canonical = canonical; job->packed = packed;
+    job->block0 = block0; job->dtype = d->dtype; job->Cin = d->Cin;
+    job->rows = d->w_rows; job->ld = d->w_ld; job->mode = 0; job->nchunks = 0; job->ntaps = d->ntaps;
+    int64_t n = (int64_t)d->w_rows * d->w_ld;
+    if (patch_enabled()) {
+        PatchPlan pp;
+        patch_fwd_plan(d, pp);
+        if (pp.ok) {
+            CVG_CHECK((int64_t)pp.nchunks * pp.T * 32 <= d->w_ld, "weight_pack_job: packed buffer too small");
+            job->mode = 1; job->nchunks = pp.nchunks; job->ntaps = pp.T;
+            n = (int64_t)d->w_rows * pp.nchunks * pp.T * 32;
+        }
+    }
+    CVG_CHECK(n % 8 == 0 && d->w_ld % 8 == 0, "weight_pack_job: packed size must be a multiple of 8");
+    job->n_groups = n / 8;
+    const int64_t blocks = (job->n_groups + 255) / 256;
+    CVG_CHECK(blocks + block0 < (1ll << 31), "weight_pack_job: too many blocks");
+    return (int)blocks;
+}
+
+int cvg_weight_pack_batch(const cvg_pack_job* jobs_dev, int32_t n_jobs, int32_t total_blocks, cvg_stream stream) {
+    CVG_CHECK(jobs_dev && n_jobs > 0 && total_blocks > 0, "weight_pack_batch: bad args");
+    weight_pack_batch<<<total_blocks, 256, 0, (hipStream_t)stream>>>(jobs_dev, n_jobs);
     CVG_LAUNCH_CHECK();
     return 0;
 }

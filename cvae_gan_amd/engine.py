@@ -20,6 +20,9 @@ Reference map (all in /root/reference):
 import math
 from collections import OrderedDict
 
+import contextlib
+import os
+
 import torch
 
 from . import ops
@@ -227,6 +230,9 @@ class Engine:
         self.device = torch.device(device)
         self.s = pix_dim // (2 ** n_stage)
         self._gemms, self._ws_bytes = [], 0
+        self.overlap = os.environ.get("CVG_NO_OVERLAP") is None     # A/B switch for benchmarking
+        self._side, self._side_dirty = None, False
+        self._pack_batch = None
         self.step_count = 0
         self.training = True
         self.grad_ready = None      # callable(stage) -> None, see cvae_gan_amd/ddp.py
@@ -473,13 +479,18 @@ class Engine:
         self.ws = torch.zeros(max(wg, self._ws_bytes, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
         max_c = max(self.ngf * 8, self.dec["nout"], 4 * self.z, self.dec["F8"])
         self.red_ws = torch.zeros(2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
+        # the weight-gradient branch of backward runs on a side stream with workspaces of its own
+        self.ws_side = torch.zeros(max(wg, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
+        self.red_ws_side = torch.zeros_like(self.red_ws)
 
     # ------------------------------------------------------------------ helpers
     def pack_weights(self, force=False):
         if not force and self._packed_version == self._param_version:
             return
-        for g in self._gemms:
-            g.pack(self)
+        if self._pack_batch is None:
+            self._pack_batch = ops.PackBatch([(g.desc, g.wmap, self.params[g.key], g.w) for g in self._gemms],
+                                             self.device)
+        self._pack_batch.run()
         ops.label_bias(self.params[EP + "conv.1.weight"], self.enc["cbias"], self.ngf, self.y)
         d = self.dec
         ops.permute_f32(self.params[DP + "fc.0.bias"], d["bias0"], d["F"])
@@ -502,13 +513,39 @@ class Engine:
 
     def _ready(self, stage):
         if self.grad_ready is not None:
+            self._join()
             self.grad_ready(stage)
 
     def _fwd(self, g, x, y, bias=None, **kw):
         ops.conv_fwd(g.desc, x, g.w, y, bias=bias, ws=self.ws, **kw)
 
     def _wgrad(self, g, x, dy, dy_ld):
-        ops.conv_wgrad(g.desc, x, dy, dy_ld, g.wmap, self.grads[g.key], self.ws)
+        ops.conv_wgrad(g.desc, x, dy, dy_ld, g.wmap, self.grads[g.key], self.ws_side)
+
+    @contextlib.contextmanager
+    def _branch(self):
+        """Launches inside run on the side stream, after everything enqueued so far on the current
+        stream.  Backward uses it for parameter gradients (weight-gradient GEMMs, bias column
+        sums): nothing downstream in backward reads them, so they overlap the input-gradient
+        chain; _join() makes the current stream wait for them."""
+        if not self.overlap:
+            yield
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            yield
+        self._side_dirty = True
+
+    def _join(self):
+        if self._side_dirty:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            torch.cuda.current_stream().wait_event(ev)
+            self._side_dirty = False
 
     # ------------------------------------------------------------------ encoder
     def enc_forward(self, x, labels):
@@ -538,34 +575,41 @@ class Engine:
     def enc_backward(self, dh):
         e, B, P, ngf = self.enc, self.B, self.P, self.ngf
         last = e["blocks"][-1]
-        self._wgrad(e["fc3"], e["f1"], dh, e["nz"])
-        ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws)
+        with self._branch():
+            self._wgrad(e["fc3"], e["f1"], dh, e["nz"])
+            ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws_side)
         self._fwd(e["fc3_dg"], dh, e["d_f1"])
         self._bn_bwd(e["d_f1"], e["f1"], e["f0"], e["d_f0"], B, e["fcd"], e["stf"], EP + "fc.1")
-        self._wgrad(e["fc0"], last["out"], e["d_f0"], e["fcd"])
-        ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws)
+        with self._branch():
+            self._wgrad(e["fc0"], last["out"], e["d_f0"], e["fcd"])
+            ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws_side)
         self._fwd(e["fc0_dg"], e["d_f0"], last["d_out"])
         self._ready("enc.head")
         for i in range(len(e["blocks"]) - 1, -1, -1):
             blk = e["blocks"][i]
             p, M, C = blk["prefix"], blk["M"], blk["cin"]
-            self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
+            with self._branch():
+                self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
             for g in blk["dgd"]:
                 self._fwd(g, blk["d_out"], blk["d_r"])
             self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
-            self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
+            with self._branch():
+                self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
             self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"])
             self._bn_bwd(blk["d_b1"], blk["b1"], blk["c1"], blk["d_c1"], M, C, blk["st1"], p + "res.res.1")
-            self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
+            with self._branch():
+                self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
             d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
             # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
             self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
             self._ready("enc.blk%d" % i)
         self._bn_bwd(e["d_a0"], e["a0"], e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
-        self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
-        ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
-                           self.grads[EP + "conv.1.bias"], self.red_ws)
+        with self._branch():
+            self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
+            ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
+                               self.grads[EP + "conv.1.bias"], self.red_ws_side)
         self._ready("enc.stem")
+        self._join()
 
     # ------------------------------------------------------------------ sampler
     def sample(self, h, eps, batch_size):
@@ -610,29 +654,34 @@ class Engine:
         d, B, P, s, ngf = self.dec, self.B, self.P, self.s, self.ngf
         ops.tanh_bwd(d_dec, d["dec"], d["dpre"], B, P, d["dpre_win"])
         last = d["ups"][-1]
-        self._wgrad(d["tail"], last["y"], d["dpre"], 8)
-        ops.colsum(d["dpre"], B * P * P, 8, 8, d["bgrad8"], self.red_ws)
-        ops.permute_f32(d["bgrad8"], self.grads[d["tail_key"] + "bias"], 3)
+        with self._branch():
+            self._wgrad(d["tail"], last["y"], d["dpre"], 8)
+            ops.colsum(d["dpre"], B * P * P, 8, 8, d["bgrad8"], self.red_ws_side)
+            ops.permute_f32(d["bgrad8"], self.grads[d["tail_key"] + "bias"], 3)
         self._fwd(d["tail_dg"], d["dpre_win"], d["dxp"])
         ops.reflect_fold(d["dxp"], last["d_y"], B, P, P, ngf, 3)
         for i in range(len(d["ups"]) - 1, -1, -1):
             up = d["ups"][i]
             M = B * 4 * up["h"] * up["h"]
-            self._wgrad(up["fwd"], up["u"], up["d_y"], up["cout"])
-            ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws)
+            with self._branch():
+                self._wgrad(up["fwd"], up["u"], up["d_y"], up["cout"])
+                ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws_side)
             self._fwd(up["dg"], up["d_y"], up["d_u"])
             d_x = d["d_x0"] if i == 0 else d["ups"][i - 1]["d_y"]
             ops.upsample_pad_bwd(up["d_u"], d_x, B, up["h"], up["h"], up["cin"])
-        self._wgrad(d["fc3"], d["g1"], d["d_x0"], d["nout"])
-        ops.colsum(d["d_x0"], B, d["nout"], d["nout"], self.grads[DP + "fc.3.bias"], self.red_ws,
-                   d["C0"], 1, s * s)
+        with self._branch():
+            self._wgrad(d["fc3"], d["g1"], d["d_x0"], d["nout"])
+            ops.colsum(d["d_x0"], B, d["nout"], d["nout"], self.grads[DP + "fc.3.bias"], self.red_ws_side,
+                       d["C0"], 1, s * s)
         self._fwd(d["fc3_dg"], d["d_x0"], d["d_g1"])
         ops.lrelu_dropout_bwd(d["d_g1"], d["g1"], mask if self.training else None, d["d_g0"], B * d["F8"])
-        self._wgrad(d["fc0"], d["zin"], d["d_g0"], d["F8"])
-        ops.colsum(d["d_g0"], B, d["F8"], d["F8"], d["bgradF8"], self.red_ws)
-        ops.permute_f32(d["bgradF8"], self.grads[DP + "fc.0.bias"], d["F"])
+        with self._branch():
+            self._wgrad(d["fc0"], d["zin"], d["d_g0"], d["F8"])
+            ops.colsum(d["d_g0"], B, d["F8"], d["F8"], d["bgradF8"], self.red_ws_side)
+            ops.permute_f32(d["bgradF8"], self.grads[DP + "fc.0.bias"], d["F"])
         self._fwd(d["fc0_dg"], d["d_g0"], d["dzin"])
         self._ready("dec")
+        self._join()
         return d["dzin"]
 
     # ------------------------------------------------------------------ fused step

@@ -6,7 +6,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check, ConvDesc, WMap, F32, BF16, PAD_ZERO, PAD_REFLECT  # noqa: F401
+from ._lib import lib, check, ConvDesc, WMap, PackJob, CvgError, F32, BF16, PAD_ZERO, PAD_REFLECT  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -53,6 +53,29 @@ def conv_wgrad_workspace(desc):
 def weight_pack(desc, wmap, canonical, packed):
     assert packed.numel() >= desc.w_rows * desc.w_ld and dt(packed) == desc.dtype
     check(lib.cvg_weight_pack(C.byref(desc), C.byref(wmap), ptr(canonical), ptr(packed), stream()))
+
+
+class PackBatch:
+    """Every packed-weight layout of a network, repacked by one launch.
+    items: (desc, wmap, canonical f32 tensor, packed tensor); the tensors must stay alive and in place."""
+
+    def __init__(self, items, device):
+        jobs = (PackJob * len(items))()
+        blocks = 0
+        for i, (desc, wmap, canonical, packed) in enumerate(items):
+            assert packed.numel() >= desc.w_rows * desc.w_ld and dt(packed) == desc.dtype
+            nb = lib.cvg_weight_pack_job(C.byref(desc), C.byref(wmap), ptr(canonical), ptr(packed), blocks,
+                                         C.byref(jobs[i]))
+            if nb < 0:
+                raise CvgError(lib.cvg_last_error().decode())
+            blocks += nb
+        self.n_jobs, self.blocks = len(items), blocks
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+        self.table = raw.to(device)
+        self._keep = items
+
+    def run(self):
+        check(lib.cvg_weight_pack_batch(ptr(self.table), self.n_jobs, self.blocks, stream()))
 
 
 def label_bias(w_stem, cbias, cout, y_dim):

@@ -111,6 +111,24 @@ int    cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int
 int cvg_weight_pack(const cvg_conv_desc* d, const cvg_wmap* map, const float* canonical,
                     void* packed, cvg_stream s);
 
+/* The same for every layout of a network in ONE launch.  cvg_weight_pack_job() fills a
+ * job record on the host (block0 = first 256-thread block of the job, the running sum of
+ * the blocks of the jobs before it) and returns the job's block count (< 0: error); the
+ * caller copies the records to device memory once and calls cvg_weight_pack_batch() after
+ * every optimiser step (the AdamW update of cvae.py:157 invalidates the packed copies). */
+typedef struct cvg_pack_job {
+    cvg_wmap map;
+    const float* canonical;
+    void* packed;
+    int64_t n_groups;            /* 8-element groups of the packed buffer               */
+    int32_t block0, mode;        /* mode 0: row-major [rows][ld], 1: fragment order     */
+    int32_t rows, ld, nchunks, ntaps, Cin, dtype;
+} cvg_pack_job;
+int cvg_weight_pack_job(const cvg_conv_desc* d, const cvg_wmap* map, const float* canonical,
+                        void* packed, int32_t block0, cvg_pack_job* job);
+int cvg_weight_pack_batch(const cvg_pack_job* jobs_dev, int32_t n_jobs, int32_t total_blocks,
+                          cvg_stream s);
+
 /* Stem label fold (encoder.forward's torch.cat of label planes, networks.py:86,
  * cvae.py:129): cbias[c][n] = sum over the 49 taps of W[n][3 + c][kh][kw].          */
 int cvg_label_bias(const float* w_stem, float* cbias, int32_t cout, int32_t y_dim,
