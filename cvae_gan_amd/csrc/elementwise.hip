@@ -450,14 +450,15 @@ __device__ __forceinline__ int unpad_reflect1(int u, int n2) {      // padded in
     return p < 0 ? 1 : (p >= n2 ? n2 - 2 : p);
 }
 
+// grid: x over (padded column, 8-channel chunk), y = padded row, z = image
 template <typename T>
-__global__ void upsample_pad_fwd(const T* __restrict__ x, T* __restrict__ u, int B, int h, int w, int C) {
+__global__ void __launch_bounds__(256) upsample_pad_fwd(const T* __restrict__ x, T* __restrict__ u, int B, int h, int w,
+                                                        int C) {
     const int CC = C / 8, UH = 2 * h + 2, UW = 2 * w + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)B * UH * UW * CC) return;
-    const int ch = (int)(i % CC);
-    const int ux = (int)((i / CC) % UW), uy = (int)((i / ((int64_t)CC * UW)) % UH);
-    const int b = (int)(i / ((int64_t)CC * UW * UH));
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= UW * CC) return;
+    const int ux = t / CC, ch = t - ux * CC;
+    const int uy = blockIdx.y, b = blockIdx.z;
     int y0, y1, x0, x1;
     float wy0, wy1, wx0, wx1;
     up_src(unpad_reflect1(uy, 2 * h), h, y0, y1, wy0, wy1);
@@ -470,51 +471,78 @@ __global__ void upsample_pad_fwd(const T* __restrict__ x, T* __restrict__ u, int
     load8<T>(base + ((size_t)y1 * w + x1) * C, d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * bb[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
-    store8<T>(u + (size_t)i * 8, o);
+    store8<T>(u + (((size_t)b * UH + uy) * UW + ux) * C + ch * 8, o);
 }
 
-// Per-axis gather list of the transpose: which padded positions feed input index i, and with what weight.
-__device__ __forceinline__ int up_bwd_list(int i, int h, int (&pos)[8], float (&wt)[8]) {
-    int n = 0;
+// Per-axis taps of the transpose: which padded positions feed input index i, and with what weight.
+// Slots 0-3: up-sampled p = 2i-1 .. 2i+2 (padded position p+1); slot 4: padded row 0, the mirror of
+// p = 1; slot 5: padded row n2+1, the mirror of p = n2-2.  Absent taps have weight 0.
+__device__ __forceinline__ void up_bwd_taps(int i, int h, int (&pos)[6], float (&wt)[6]) {
     const int n2 = 2 * h;
-    for (int p = 2 * i - 1; p <= 2 * i + 2; ++p) {
-        if (p < 0 || p >= n2) continue;
-        int i0, i1;
-        float w0, w1;
-        up_src(p, h, i0, i1, w0, w1);
-        const float wgt = (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
-        if (wgt == 0.f) continue;
-        pos[n] = p + 1; wt[n] = wgt; ++n;
-        if (p == 1) { pos[n] = 0; wt[n] = wgt; ++n; }                  // padded row 0 mirrors p = 1
-        if (p == n2 - 2) { pos[n] = n2 + 1; wt[n] = wgt; ++n; }        // padded row n2+1 mirrors p = n2-2
+    pos[4] = 0; wt[4] = 0.f;
+    pos[5] = n2 + 1; wt[5] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = 2 * i - 1 + k;
+        float wgt = 0.f;
+        if (p >= 0 && p < n2) {
+            int i0, i1;
+            float w0, w1;
+            up_src(p, h, i0, i1, w0, w1);
+            wgt = (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
+        }
+        pos[k] = p >= 0 && p < n2 ? p + 1 : 0;
+        wt[k] = wgt;
+        if (p == 1) wt[4] = wgt;
+        if (p == n2 - 2) wt[5] = wgt;
     }
-    return n;
 }
 
+// grid: x over (column, 8-channel chunk), y = row, z = image
 template <typename T>
-__global__ void upsample_pad_bwd(const T* __restrict__ du, T* __restrict__ dx, int B, int h, int w, int C) {
+__global__ void __launch_bounds__(256) upsample_pad_bwd(const T* __restrict__ du, T* __restrict__ dx, int B, int h, int w,
+                                                        int C) {
     const int CC = C / 8, UH = 2 * h + 2, UW = 2 * w + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)B * h * w * CC) return;
-    const int ch = (int)(i % CC);
-    const int ix = (int)((i / CC) % w), iy = (int)((i / ((int64_t)CC * w)) % h);
-    const int b = (int)(i / ((int64_t)CC * w * h));
-    int py[8], px[8];
-    float wy[8], wx[8];
-    const int ny = up_bwd_list(iy, h, py, wy), nx = up_bwd_list(ix, w, px, wx);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= w * CC) return;
+    const int ix = t / CC, ch = t - ix * CC;
+    const int iy = blockIdx.y, b = blockIdx.z;
+    int py[6], px[6];
+    float wy[6], wx[6];
+    up_bwd_taps(iy, h, py, wy);
+    up_bwd_taps(ix, w, px, wx);
     const T* base = du + (size_t)b * UH * UW * C + ch * 8;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int a = 0; a < ny; ++a)
-        for (int c = 0; c < nx; ++c) {
-            float v[8];
-            load8<T>(base + ((size_t)py[a] * UW + px[c]) * C, v);
+    // the 4 x 4 window every pixel has: all 16 loads in flight together
+    float v[4][4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) load8<T>(base + ((size_t)py[a] * UW + px[c]) * C, v[a][c]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
             const float wgt = wy[a] * wx[c];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += wgt * v[j];
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * v[a][c][j];
         }
-    store8<T>(dx + (size_t)i * 8, acc);
+    // mirror taps: only the two rows / columns next to each border have them
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if (a < 4 && c < 4) continue;
+            const float wgt = wy[a] * wx[c];
+            if (wgt == 0.f) continue;
+            float e[8];
+            load8<T>(base + ((size_t)py[a] * UW + px[c]) * C, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * e[j];
+        }
+    store8<T>(dx + (((size_t)b * h + iy) * w + ix) * C + ch * 8, acc);
 }
 
 // transpose of ReflectionPad2d(pad)
@@ -847,16 +875,18 @@ int cvg_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, cvg_stream stream)
 int cvg_upsample_pad_fwd(const void* x, void* u, int32_t dtype, int32_t B, int32_t h, int32_t w, int32_t C,
                          cvg_stream stream) {
     CVG_CHECK(x && u && B > 0 && h > 0 && w > 0 && C % 8 == 0, "upsample_pad_fwd: bad args");
-    const int64_t n = (int64_t)B * (2 * h + 2) * (2 * w + 2) * (C / 8);
-    DISPATCH(dtype, upsample_pad_fwd<T><<<grid1(n), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)u, B, h, w, C));
+    CVG_CHECK(2 * h + 2 <= 65535 && B <= 65535, "upsample_pad_fwd: grid too large");
+    const dim3 grid(grid1((int64_t)(2 * w + 2) * (C / 8)), 2 * h + 2, B);
+    DISPATCH(dtype, upsample_pad_fwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)u, B, h, w, C));
     CVG_LAUNCH_CHECK();
     return 0;
 }
 int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int32_t h, int32_t w, int32_t C,
                          cvg_stream stream) {
     CVG_CHECK(du && dx && B > 0 && h > 0 && w > 0 && C % 8 == 0, "upsample_pad_bwd: bad args");
-    const int64_t n = (int64_t)B * h * w * (C / 8);
-    DISPATCH(dtype, upsample_pad_bwd<T><<<grid1(n), 256, 0, (hipStream_t)stream>>>((const T*)du, (T*)dx, B, h, w, C));
+    CVG_CHECK(h <= 65535 && B <= 65535, "upsample_pad_bwd: grid too large");
+    const dim3 grid(grid1((int64_t)w * (C / 8)), h, B);
+    DISPATCH(dtype, upsample_pad_bwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)du, (T*)dx, B, h, w, C));
     CVG_LAUNCH_CHECK();
     return 0;
 }
