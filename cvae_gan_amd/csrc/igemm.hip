@@ -67,7 +67,7 @@ __device__ __forceinline__ bool pad_coord(const Geom& g, int& iy, int& ix) {
 // forward / input-gradient kernel
 // ================================================================================
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) igemm_fwd(const FwdArgs a) {
+__device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zsplit) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int BK = 8 * VEC;                 // 128 bytes of k per row and step
     constexpr int PITCH = 144;                  // LDS row pitch: 128 B + 16 B pad (conflict-free b128 reads)
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) igemm_fwd(const FwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-    const int ks_beg = blockIdx.z * a.nk_per_split;
+    const int ks_beg = zsplit * a.nk_per_split;
     const int ks_end = min(a.nk_total, ks_beg + a.nk_per_split);
 
     if (ks_beg < ks_end) {
@@ -178,59 +178,103 @@ __global__ void __launch_bounds__(256) igemm_fwd(const FwdArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = n][col = m]; lane owns pixel column l31, 4 consecutive n per register group
+    // ---- epilogue: D[row = n][col = m]; lane owns pixel column l31, 4 consecutive n per register group.
+    // Split-K partials go straight to the workspace; final values are staged in LDS (free after the
+    // loop's last barrier) and leave as whole rows, 16 bytes per lane.
     T* __restrict__ yp = (T*)a.y;
     const T* __restrict__ resp = (const T*)a.res;
     const T* __restrict__ gatep = (const T*)a.gate;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int OP = BN * ES + 16;             // staged row pitch
+    static_assert(BM * OP <= 2 * STAGE, "output tile must fit the operand buffers");
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * WTM + mi * 32 + l31;
-        if (m >= g.M) continue;
+        const int ml = wm * WTM + mi * 32 + l31, m = m0 + ml;
+        const bool live = m < g.M;
+        const uint32_t b = fdiv(live ? m : 0, g.div_ohw);
+        const uint32_t rem = (live ? m : 0) - b * g.OHW;
+        const uint32_t oy = fdiv(rem, g.div_ow);
+        const uint32_t ox = rem - oy * g.OW;
+        const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
+                            (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+        const float* cb = (a.cbias && live) ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * WTN + ni * 32 + 8 * q + 4 * h, n = n0 + nl;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j];
+                if (a.ksplit > 1) {
+                    if (live && n < a.N) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(a.ws + ((size_t)zsplit * g.M + m) * a.N + n) = o;
+                    }
+                    continue;
+                }
+                if (live && n < a.N) {
+                    if (a.bias) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
+                    }
+                    if (cb) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
+                    }
+                    if (resp) {
+                        float r[4];
+                        load4<T>(resp + yoff + n, r);
+                        if (gatep) {
+                            float gt[4];
+                            load4<T>(gatep + yoff + n, gt);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += r[j];
+                    }
+                }
+                store4<T>((T*)(smem + ml * OP) + nl, v);
+            }
+        }
+    }
+    if (a.ksplit > 1) return;                    // uniform over the grid
+    __syncthreads();
+    constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
+    constexpr int EPP = 16 / ES;
+#pragma unroll
+    for (int i = 0; i < BM * PPR / 256; ++i) {
+        const int idx = tid + 256 * i;
+        const int ml = idx / PPR, pc = idx % PPR;
+        const int m = m0 + ml, n = n0 + pc * EPP;
+        if (m >= g.M || n >= a.N) continue;
         const uint32_t b = fdiv(m, g.div_ohw);
         const uint32_t rem = m - b * g.OHW;
         const uint32_t oy = fdiv(rem, g.div_ow);
         const uint32_t ox = rem - oy * g.OW;
         const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
                             (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
-        const float* cb = a.cbias ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * WTN + ni * 32 + 8 * q + 4 * h;
-                if (n >= a.N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j];
-                if (a.ksplit > 1) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(a.ws + ((size_t)blockIdx.z * g.M + m) * a.N + n) = o;
-                    continue;
-                }
-                if (a.bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
-                }
-                if (cb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
-                }
-                if (resp) {
-                    float r[4];
-                    load4<T>(resp + yoff + n, r);
-                    if (gatep) {
-                        float gt[4];
-                        load4<T>(gatep + yoff + n, gt);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += r[j];
-                }
-                store4<T>(yp + yoff + n, v);
-            }
+        const u32x4 v = *(const u32x4*)(smem + ml * OP + pc * 16);
+        if (n + EPP <= a.N) {
+            *(u32x4*)(yp + yoff + n) = v;
+        } else {                                 // N is a multiple of 4: half a 16-bit piece
+            *(unsigned long long*)(yp + yoff + n) = ((unsigned long long)v[1] << 32) | v[0];
         }
     }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_fwd(const FwdArgs a) {
+    igemm_fwd_tile<T, BM, BN, WM, WN>(a, blockIdx.z);
+}
+
+// Up to four convolutions over the same output grid in one launch (blockIdx.z picks one): the
+// output-parity classes of a stride-2 convolution's input gradient.
+struct FwdArgsGroup { FwdArgs a[4]; };
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_fwd_group(const FwdArgsGroup m) {
+    igemm_fwd_tile<T, BM, BN, WM, WN>(m.a[blockIdx.z], 0);
 }
 
 // split-K finish: y[m][n] = sum_z ws[z][m][n] + bias[n]   (dense rows of y_ld)
@@ -475,7 +519,7 @@ int fwd_ksplit(const cvg_conv_desc* d, int M, bool dense) {
     const int BK = bk_of(d->dtype);
     const int nk = ceil_div((int64_t)d->ntaps * d->Cin, BK);
     const int tiles = ceil_div(M, 128) * ceil_div(d->N, 128);
-    if (!dense || tiles >= 64 || nk < 16) return 1;
+    if (!dense || tiles >= 192 || nk < 16) return 1;
     int ks = 256 / tiles;
     if (ks > nk / 4) ks = nk / 4;
     if (ks > 64) ks = 64;
@@ -506,6 +550,23 @@ int launch_fwd(const cvg_conv_desc* d, FwdArgs& a, hipStream_t s) {
         splitk_finish<T><<<ceil_div(n, 256), 256, 0, s>>>(a.ws, (T*)a.y, a.bias, M, N, d->y_pix_pitch, a.ksplit);
         CVG_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+template <typename T>
+int launch_fwd_group(int n, int M, int N, const FwdArgsGroup& m, hipStream_t s) {
+    dim3 blk(256);
+    if (N > 64) {
+        dim3 grid(ceil_div(M, 128), ceil_div(N, 128), n);
+        igemm_fwd_group<T, 128, 128, 2, 2><<<grid, blk, 0, s>>>(m);
+    } else if (N > 32) {
+        dim3 grid(ceil_div(M, 256), 1, n);
+        igemm_fwd_group<T, 256, 64, 4, 1><<<grid, blk, 0, s>>>(m);
+    } else {
+        dim3 grid(ceil_div(M, 256), 1, n);
+        igemm_fwd_group<T, 256, 32, 4, 1><<<grid, blk, 0, s>>>(m);
+    }
+    CVG_LAUNCH_CHECK();
     return 0;
 }
 
@@ -580,6 +641,41 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     if (a.ksplit > 1)
         CVG_CHECK(ws && ws_bytes >= (size_t)a.ksplit * a.g.M * d->N * sizeof(float), "conv_fwd: workspace too small");
     return d->dtype == CVG_BF16 ? launch_fwd<bf16>(d, a, s) : launch_fwd<float>(d, a, s);
+}
+
+int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x, const void* const* w, void* y,
+                       cvg_stream stream) {
+    CVG_CHECK(n >= 1 && n <= 4 && descs && x && w && y, "conv_fwd_group: bad args");
+    FwdArgsGroup m;
+    const cvg_conv_desc* d0 = &descs[0];
+    for (int i = 0; i < n; ++i) {
+        const cvg_conv_desc* d = &descs[i];
+        FwdArgs& a = m.a[i];
+        if (make_geom(d, a.g)) return -1;
+        const int BK = bk_of(d->dtype);
+        CVG_CHECK(d->dtype == d0->dtype && d->N == d0->N && a.g.M == m.a[0].g.M,
+                  "conv_fwd_group: members must share dtype, N and the output grid");
+        CVG_CHECK(d->N > 0 && d->N % 4 == 0, "conv_fwd_group: N %d must be a multiple of 4", d->N);
+        CVG_CHECK(d->w_ld % BK == 0 && d->w_ld >= a.g.Kvalid, "conv_fwd_group: w_ld %d does not cover K %d", d->w_ld, a.g.Kvalid);
+        CVG_CHECK(d->w_rows % 128 == 0 && d->w_rows >= d->N, "conv_fwd_group: w_rows %d must be N padded to 128", d->w_rows);
+        CVG_CHECK(d->y_pix_pitch % 4 == 0 && d->y_row_pitch % 4 == 0 && d->y_img_pitch % 4 == 0, "conv_fwd_group: y pitches");
+        CVG_CHECK(w[i], "conv_fwd_group: null weights");
+        if (patch_enabled()) {                   // members are packed for the gather kernel
+            PatchPlan pp;
+            patch_fwd_plan(d, pp);
+            CVG_CHECK(!pp.ok, "conv_fwd_group: member %d belongs to the patch kernel", i);
+        }
+        a.x = x; a.w = w[i]; a.y = y; a.bias = nullptr; a.cbias = nullptr; a.labels = nullptr; a.res = nullptr;
+        a.gate = nullptr; a.ws = nullptr; a.N = d->N; a.w_ld = d->w_ld;
+        a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
+        a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
+        a.nk_total = ceil_div(a.g.Kvalid, BK);
+        a.ksplit = 1; a.nk_per_split = a.nk_total;
+    }
+    for (int i = n; i < 4; ++i) m.a[i] = m.a[0];
+    hipStream_t s = (hipStream_t)stream;
+    return d0->dtype == CVG_BF16 ? launch_fwd_group<bf16>(n, m.a[0].g.M, d0->N, m, s)
+                                 : launch_fwd_group<float>(n, m.a[0].g.M, d0->N, m, s);
 }
 
 const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {

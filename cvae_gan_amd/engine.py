@@ -374,6 +374,7 @@ class Engine:
             blk["conv1"], blk["dg1"] = self._conv3x3_plans(p + "res.res.0.weight", B, H, cin, cin, 1)
             blk["conv2"], blk["dg2"] = self._conv3x3_plans(p + "res.res.3.weight", B, H, cin, cin, 1)
             blk["down"], blk["dgd"] = self._conv3x3_plans(p + "conv.weight", B, H, cin, cout, 2)
+            blk["dgd_group"] = ops.ConvGroup([g.desc for g in blk["dgd"]], [g.w for g in blk["dgd"]])
             for name in ("c1", "b1", "c2", "r", "d_r", "d_c2", "d_b1", "d_c1"):
                 blk[name] = self._t(M, cin)
             blk["st1"], blk["st2"] = self._f(2, cin), self._f(2, cin)
@@ -590,8 +591,11 @@ class Engine:
             p, M, C = blk["prefix"], blk["M"], blk["cin"]
             with self._branch():
                 self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
-            for g in blk["dgd"]:
-                self._fwd(g, blk["d_out"], blk["d_r"])
+            if blk["cin"] > 64:
+                blk["dgd_group"].run(blk["d_out"], blk["d_r"])
+            else:                                   # narrow outputs: the classes run faster one after another
+                for g in blk["dgd"]:
+                    self._fwd(g, blk["d_out"], blk["d_r"])
             self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
             with self._branch():
                 self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)

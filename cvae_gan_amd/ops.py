@@ -46,6 +46,20 @@ def conv_wgrad(desc, x, dy, dy_ld, wmap, grad, ws, accumulate=False):
                              ptr(ws), ws.numel() * ws.element_size(), stream()))
 
 
+class ConvGroup:
+    """Up to four convolutions of one input over one output grid, launched together."""
+
+    def __init__(self, descs, weights):
+        assert 1 <= len(descs) <= 4 and len(descs) == len(weights)
+        self.n = len(descs)
+        self.descs = (ConvDesc * self.n)(*descs)
+        self.w = (C.c_void_p * self.n)(*[ptr(w) for w in weights])
+        self._keep = weights
+
+    def run(self, x, y):
+        check(lib.cvg_conv_fwd_group(self.n, self.descs, ptr(x), self.w, ptr(y), stream()))
+
+
 def conv_wgrad_workspace(desc):
     return int(lib.cvg_conv_wgrad_workspace(C.byref(desc)))
 

@@ -80,6 +80,14 @@ int    cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* 
                     const void* res, const void* gate, void* ws, size_t ws_bytes,
                     cvg_stream s);
 
+/* Up to four convolutions of the same input over the same output grid in ONE launch (same
+ * dtype, N, B, OH, OW; each with its own taps, packed weights and output offsets): the four
+ * output-parity classes of the input gradient of the stride-2 convolutions
+ * (ConvResBlock's conv3x3 stride 2, networks.py:198-221).  No bias / residual epilogue.
+ * descs points to n consecutive descriptors, w to n packed-weight pointers.               */
+int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x,
+                       const void* const* w, void* y, cvg_stream s);
+
 /* Weight gradient:  dWg[n][k] = sum_m dY[m][n] * gather(x)[m][k], then scattered to
  * the canonical (reference-layout) f32 gradient through `map`.
  * Replaces the weight-gradient half of autograd for the layers listed above.
