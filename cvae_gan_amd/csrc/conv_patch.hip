@@ -336,8 +336,9 @@ struct PatchWgradArgs {
     int OH, OW, dy_ld, dy_cols;
     int patch_px, ntiles, tiles_per_split, tiles_per_group;
     int n_rows, k_ld;
+    int nchunks, nchunks_ntiles, xcd_remap;
     TileGeom t;
-    FastDiv div_tpg;
+    FastDiv div_tpg, div_chunks, div_cn;
 };
 
 // Transposed operand fetch with per-pixel addresses: slot (h, j) of the fragment is tile
@@ -420,13 +421,25 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WT, wt = wave % WT;
     const int l31 = lane & 31, h = lane >> 5;
-    const int chunk = blockIdx.x, n0 = blockIdx.y * BNW;
+    // Workgroups are dealt to the 8 XCDs round-robin by launch index.  Renumber them so that each
+    // XCD owns one contiguous range of (split, n tile, chunk) with the chunk fastest: the
+    // workgroups that read the same dY tile (all chunks of one n tile and split) then run at the
+    // same time behind the same L2 instead of fetching it once per XCD.
+    int wg = blockIdx.x;
+    if (a.xcd_remap) {
+        const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = wg & 7;
+        wg = xcd * per + min(xcd, rem) + (wg >> 3);
+    }
+    const int zq = fdiv(wg, a.div_cn);                        // split
+    const int cn = wg - zq * a.nchunks_ntiles;
+    const int nt = fdiv(cn, a.div_chunks);
+    const int chunk = cn - nt * a.nchunks, n0 = nt * BNW;
     const T* __restrict__ xp = (const T*)a.x;
     const T* __restrict__ gp = (const T*)a.dy;
     char* Ps = smem;
     char* Gs = smem + ((a.patch_px * PP + 255) & ~255);
 
-    const int tl_beg = blockIdx.z * a.tiles_per_split;
+    const int tl_beg = zq * a.tiles_per_split;
     const int tl_end = min(a.ntiles, tl_beg + a.tiles_per_split);
     const int nitems = a.patch_px * CPP;
 
@@ -536,7 +549,7 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
     }
 
     // partials [split][n][tap * Cin + chunk*32 + c], D[row = n][col = c]
-    float* out = a.ws + (size_t)blockIdx.z * a.n_rows * a.k_ld;
+    float* out = a.ws + (size_t)zq * a.n_rows * a.k_ld;
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         const int tap = tap0 + tt;
@@ -549,6 +562,221 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
                 const int n = n0 + (wn * NI + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 out[(size_t)n * a.k_ld + k] = acc[ni][tt][r];
             }
+    }
+}
+
+
+// --------------------------------------------------------------------------------------
+// 3x3 kernels in bf16 with >= 64 output channels.  A wave owns 32 output channels x all nine
+// taps x one 32-channel chunk (nine accumulators, no idle tap slots); WN waves split the
+// output channels, WC waves take neighbouring chunks (WC = 2 for 64-channel layers, so a dY
+// tile still feeds four waves).  Tiles are 128 pixels and double-buffered in LDS: the next
+// tile is fetched to registers during the MFMAs, stored into the other buffer after them, and
+// one barrier per tile separates the generations.
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_read2(const char* base, int o0, int o1) {
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + o0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + o1));
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+    return r;
+}
+
+template <int WN, int WC>
+__global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgradArgs a) {
+    typedef bf16 T;
+    constexpr int ES = 2, TAPS = 9;
+    constexpr int BNW = 32 * WN;                               // output channels per workgroup
+    constexpr int TPX = 128, NSUB = TPX / 16;                  // tile pixels, 16-pixel MFMA sub-steps
+    constexpr int CPP = CK * ES / 16;                          // 16-byte pieces per patch pixel and chunk
+    constexpr int PP = CK * ES;                                // patch pixel pitch (one chunk)
+    constexpr int GW = BNW * ES, PG = GW == 64 ? GW : GW + 64; // dY row bytes / pitch
+    constexpr int NT = 64 * WN * WC;                           // threads: 4 waves, or 8 (two per SIMD)
+    constexpr bool LEAN = NT == 512;                           // 256 registers per wave: no second fragment set
+    constexpr int GPR = GW / 16, GIT = TPX * GPR / NT;         // dY pieces per row / per thread
+    constexpr int NIT = 256 * CPP * WC / NT;                   // patch pieces per thread (patch_px <= 256)
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const TileGeom& t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WC, wc = wave % WC;
+    const int l31 = lane & 31, h = lane >> 5;
+    int wg = blockIdx.x;
+    if (a.xcd_remap) {                                         // see patch_wgrad
+        const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = wg & 7;
+        wg = xcd * per + min(xcd, rem) + (wg >> 3);
+    }
+    const int zq = fdiv(wg, a.div_cn);
+    const int cn = wg - zq * a.nchunks_ntiles;
+    const int nt = fdiv(cn, a.div_chunks);
+    const int cg = cn - nt * a.nchunks, n0 = nt * BNW;         // cg: group of WC chunks
+    const T* __restrict__ xp = (const T*)a.x;
+    const T* __restrict__ gp = (const T*)a.dy;
+    const int chunk_stride = a.patch_px * PP;
+    const int patch_bytes = (WC * chunk_stride + 255) & ~255;
+    const int buf_bytes = patch_bytes + TPX * PG;
+
+    const int tl_beg = zq * a.tiles_per_split;
+    const int tl_end = min(a.ntiles, tl_beg + a.tiles_per_split);
+    const int nitems = a.patch_px * CPP * WC;
+
+    // Per piece, fixed for the whole kernel: element offset relative to the tile origin and the
+    // packed (image, row, column) within the patch / tile for the bounds test (zero padding only).
+    // A tile then costs one scalar origin and a few adds and compares per piece.
+    constexpr unsigned NONE = 0xFFFFFFFFu;
+    int prel[NIT], grel[GIT];
+    unsigned pgeo[NIT], ggeo[GIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + NT * i;
+        prel[i] = 0; pgeo[i] = NONE;
+        if (idx < nitems) {
+            const int p = idx / (CPP * WC), cc = idx % (CPP * WC);           // cc: piece within WC*64 bytes
+            const int tb = fdiv(p, t.div_phw);
+            const int rr = p - tb * (t.PH * t.PW);
+            const int py = fdiv(rr, t.div_pw), px = rr - py * t.PW;
+            prel[i] = tb * a.x_img_pitch + py * a.x_row_pitch + px * a.x_pix_pitch + cg * (CK * WC) + cc * (16 / ES);
+            pgeo[i] = (unsigned)tb << 16 | (unsigned)py << 8 | (unsigned)px;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GIT; ++i) {
+        const int idx = tid + NT * i;
+        const int q = idx / GPR, ci = idx % GPR;
+        grel[i] = 0; ggeo[i] = NONE;
+        const int col = n0 + ci * (16 / ES);
+        if (q < t.npx && col + (16 / ES) <= a.dy_cols) {
+            int tb, ty, tx;
+            tile_px(t, q, tb, ty, tx);
+            grel[i] = ((tb * a.OH + ty) * a.OW + tx) * a.dy_ld + col;
+            ggeo[i] = (unsigned)tb << 16 | (unsigned)ty << 8 | (unsigned)tx;
+        }
+    }
+    u32x4 pv[NIT], gv[GIT];
+    auto load_tile = [&](int tl) __attribute__((always_inline)) {
+        const int grp = fdiv(tl, a.div_tpg);
+        const int r = tl - grp * a.tiles_per_group;
+        const int tile_y = fdiv(r, t.div_tx), tile_x = r - tile_y * t.tiles_x;
+        const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = grp * t.TB;
+        const int iy0 = y0 + a.off_y, ix0 = x0 + a.off_x;
+        const T* xt = xp + ((ptrdiff_t)b0 * a.x_img_pitch + (ptrdiff_t)iy0 * a.x_row_pitch + (ptrdiff_t)ix0 * a.x_pix_pitch);
+        const T* gt = gp + ((ptrdiff_t)(b0 * a.OH + y0) * a.OW + x0) * a.dy_ld;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const unsigned g = pgeo[i];
+            const int b = b0 + (int)(g >> 16), iy = iy0 + (int)((g >> 8) & 255u), ix = ix0 + (int)(g & 255u);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (g != NONE && b < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *(const u32x4*)(xt + prel[i]);
+            pv[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < GIT; ++i) {
+            const unsigned g = ggeo[i];
+            const int b = b0 + (int)(g >> 16), oy = y0 + (int)((g >> 8) & 255u), ox = x0 + (int)(g & 255u);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (g != NONE && b < a.B && oy < a.OH && ox < a.OW) v = *(const u32x4*)(gt + grel[i]);
+            gv[i] = v;
+        }
+    };
+    auto store_tile = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < nitems) {
+                const int p = idx / (CPP * WC), cc = idx % (CPP * WC);
+                *(u32x4*)(buf + (cc / CPP) * chunk_stride + p * PP + (cc % CPP) * 16) = pv[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GIT; ++i) {
+            const int idx = tid + NT * i;
+            *(u32x4*)(buf + patch_bytes + (idx / GPR) * PG + (idx % GPR) * 16) = gv[i];
+        }
+    };
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int tt = 0; tt < TAPS; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+
+    int toff[TAPS];
+#pragma unroll
+    for (int tt = 0; tt < TAPS; ++tt) toff[tt] = ((tt / 3) * t.PW + (tt % 3)) * PP;
+
+    // LDS offsets (within a buffer) of this lane's rows at tap (0, 0) / of its dY rows, per sub-step:
+    // fragment slot (h, j) is tile pixel 16 s + 8 h + j
+    // (the eight-wave form recomputes them per sub-step instead of holding 32 registers)
+    constexpr int NROW = LEAN ? 1 : NSUB;
+    int prow[NROW][2], grow[NROW][2];
+    const int lq = (lane & 15) >> 2, cofs = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto row_offsets = [&](int s_, int (&pr)[2], int (&gr)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int qq = s_ * 16 + 8 * h + lq + 4 * e;
+            int tb, ty, tx;
+            tile_px(t, qq < t.npx ? qq : 0, tb, ty, tx);
+            pr[e] = wc * chunk_stride + ((tb * t.PH + ty) * t.PW + tx) * PP + cofs;
+            gr[e] = patch_bytes + qq * PG + wn * 64 + cofs;
+        }
+    };
+    if (!LEAN) {
+#pragma unroll
+        for (int s_ = 0; s_ < NSUB; ++s_) row_offsets(s_, prow[s_ % NROW], grow[s_ % NROW]);
+    }
+
+    if (tl_beg < tl_end) {
+        load_tile(tl_beg);
+        store_tile(smem);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tl = tl_beg; tl < tl_end; ++tl) {
+        const bool more = tl + 1 < tl_end;
+        if (more) load_tile(tl + 1);
+        const char* buf = smem + cur * buf_bytes;
+        constexpr int NSET = LEAN ? 1 : 2;
+        bf16x8 gf[NSET], xf[NSET][TAPS];
+        auto read_sub = [&](int s_, bf16x8& g, bf16x8 (&x)[TAPS]) __attribute__((always_inline)) {
+            if (LEAN) row_offsets(s_, prow[0], grow[0]);
+            g = tr_read2(buf, grow[s_ % NROW][0], grow[s_ % NROW][1]);
+#pragma unroll
+            for (int tt = 0; tt < TAPS; ++tt) x[tt] = tr_read2(buf + toff[tt], prow[s_ % NROW][0], prow[s_ % NROW][1]);
+        };
+        if (!LEAN) read_sub(0, gf[0], xf[0]);
+        // all NSUB sub-steps run even for a short tile: its missing pixels have zero dY rows
+#pragma unroll
+        for (int s_ = 0; s_ < NSUB; ++s_) {
+            if (LEAN) {
+                // the SIMD's other wave covers the LDS round trip
+                read_sub(s_, gf[0], xf[0]);
+            } else if (s_ + 1 < NSUB) {
+                read_sub(s_ + 1, gf[(s_ + 1) % NSET], xf[(s_ + 1) % NSET]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TAPS; ++tt) mma32(acc[tt], gf[s_ % NSET], xf[s_ % NSET][tt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+        if (more) store_tile(smem + cur * buf_bytes);
+        __syncthreads();
+    }
+
+    // partials [split][n][tap * Cin + chunk*32 + c], D[row = n][col = c]
+    float* out = a.ws + (size_t)zq * a.n_rows * a.k_ld;
+#pragma unroll
+    for (int tt = 0; tt < TAPS; ++tt) {
+        const int k = tt * a.Cin + (cg * WC + wc) * CK + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)n * a.k_ld + k] = acc[tt][r];
+        }
     }
 }
 
@@ -619,8 +847,14 @@ int launch_patch_fwd(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
 template <typename T, int WN, int WT, int TPW, int NI>
 int launch_patch_wgrad(const PatchWgradPlan& p, const PatchWgradArgs& a, hipStream_t s) {
     if (set_lds(patch_wgrad<T, WN, WT, TPW, NI>, p.lds_bytes)) return -1;
-    dim3 grid(p.nchunks, p.n_tiles, p.nsplit);
-    patch_wgrad<T, WN, WT, TPW, NI><<<grid, 256, p.lds_bytes, s>>>(a);
+    PatchWgradArgs b = a;
+    b.nchunks = p.nchunks; b.nchunks_ntiles = p.nchunks * p.n_tiles;
+    static const bool no_remap = getenv("CVG_NO_XCD_REMAP") != nullptr;   // A/B switch for benchmarking
+    b.xcd_remap = no_remap ? 0 : 1;
+    b.div_chunks = make_fastdiv(p.nchunks); b.div_cn = make_fastdiv(b.nchunks_ntiles);
+    const int64_t nwg = (int64_t)b.nchunks_ntiles * p.nsplit;
+    if (nwg >= (1ll << 31)) CVG_FAIL("patch_wgrad: too many workgroups");
+    patch_wgrad<T, WN, WT, TPW, NI><<<(int)nwg, 256, p.lds_bytes, s>>>(b);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -700,6 +934,36 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     if (!patch_eligible(d)) return;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
+    p.nine = 0;
+    static const bool no_nine = getenv("CVG_WGRAD_V1") != nullptr;           // A/B switch for benchmarking
+    if (!no_nine && d->dtype == CVG_BF16 && d->KW == 3 && d->ntaps == 9 && d->N > 32 && d->x_pix_pitch == d->Cin &&
+        d->pad_mode == CVG_PAD_ZERO) {
+        // chunks per workgroup: two, with eight waves for wide layers (a dY tile then feeds twice the
+        // MFMA work per byte fetched) and four waves for 64-channel ones
+        static const bool no8 = getenv("CVG_WGRAD_4W") != nullptr;            // A/B switch for benchmarking
+        const int wc = (d->N > 64 && (no8 || d->Cin % (2 * CK) != 0)) ? 1 : 2;
+        const int wn9 = d->N > 64 ? 4 : 2;
+        if (d->Cin % (CK * wc) == 0 &&
+            choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 256, p.TB, p.TH, p.TW)) {
+            p.WN = wn9; p.WT = wc; p.BNW = 32 * p.WN;
+            p.PH = p.TH + 2; p.PW = p.TW + 2;
+            p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
+            p.ntiles = p.tiles_y * p.tiles_x * p.groups;
+            p.patch_px = p.TB * p.PH * p.PW;
+            p.nchunks = d->Cin / (CK * wc);                                   // chunk groups
+            p.n_tiles = ceil_div(d->N, p.BNW);
+            const double eff9 = (double)d->B * d->OH * d->OW / ((double)p.ntiles * 128);
+            int want9 = ceil_div(256, p.nchunks * p.n_tiles);
+            if (want9 > p.ntiles) want9 = p.ntiles;
+            if (want9 < 1) want9 = 1;
+            p.tiles_per_split = ceil_div(p.ntiles, want9);
+            p.nsplit = ceil_div(p.ntiles, p.tiles_per_split);
+            const int gw = p.BNW * 2, pg = gw == 64 ? gw : gw + 64;
+            p.lds_bytes = 2 * ((size_t)((wc * p.patch_px * CK * 2 + 255) & ~255) + (size_t)128 * pg);
+            p.ws_bytes = (size_t)p.nsplit * (p.n_tiles * p.BNW) * ((size_t)p.T * d->Cin) * sizeof(float);
+            if (eff9 >= 0.5 && p.lds_bytes <= 160 * 1024) { p.nine = 1; p.ok = 1; return; }
+        }
+    }
     // waves: WN over 32*NI-channel blocks x WT over tap groups.  Wide layers give every wave two
     // channel blocks, so each patch fragment read from LDS feeds two MFMAs.
     int ni = 1;
@@ -750,7 +1014,27 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     a.div_tpg = make_fastdiv(a.tiles_per_group);
     const int tpw = p.T == 7 ? (p.WN == 1 ? 3 : 5) : ceil_div(p.T, p.WT);
     int rc = -1;
-    if (d->dtype == CVG_BF16) {
+    if (p.nine) {
+        PatchWgradArgs b = a;
+        b.nchunks = p.nchunks; b.nchunks_ntiles = p.nchunks * p.n_tiles;
+        b.div_chunks = make_fastdiv(p.nchunks); b.div_cn = make_fastdiv(b.nchunks_ntiles);
+        static const bool no_remap = getenv("CVG_NO_XCD_REMAP") != nullptr;
+        b.xcd_remap = no_remap ? 0 : 1;
+        const int64_t nwg = (int64_t)b.nchunks_ntiles * p.nsplit;
+        if (nwg >= (1ll << 31)) CVG_FAIL("patch_wgrad: too many workgroups");
+        if (p.WT == 1) {
+            if (set_lds(patch_wgrad9<4, 1>, p.lds_bytes)) return -1;
+            patch_wgrad9<4, 1><<<(int)nwg, 256, p.lds_bytes, s>>>(b);
+        } else if (p.WN == 4) {
+            if (set_lds(patch_wgrad9<4, 2>, p.lds_bytes)) return -1;
+            patch_wgrad9<4, 2><<<(int)nwg, 512, p.lds_bytes, s>>>(b);
+        } else {
+            if (set_lds(patch_wgrad9<2, 2>, p.lds_bytes)) return -1;
+            patch_wgrad9<2, 2><<<(int)nwg, 256, p.lds_bytes, s>>>(b);
+        }
+        CVG_LAUNCH_CHECK();
+        rc = 0;
+    } else if (d->dtype == CVG_BF16) {
         if (p.BNW == 128 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5, 2>(p, a, s);
         else if (p.WN == 2 && tpw == 5) rc = launch_patch_wgrad<bf16, 2, 2, 5, 1>(p, a, s);
         else if (p.WN == 1 && tpw == 3) rc = launch_patch_wgrad<bf16, 1, 4, 3, 1>(p, a, s);
