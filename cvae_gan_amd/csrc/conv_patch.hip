@@ -443,42 +443,71 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
     const int tl_end = min(a.ntiles, tl_beg + a.tiles_per_split);
     const int nitems = a.patch_px * CPP;
 
+    // Per piece, fixed for the whole kernel: element offset relative to the tile origin and the
+    // packed (image, row, column) within the patch / tile for the bounds test.  Zero padding tests
+    // the coordinates; reflection recomputes the address (slow path, the 7x7 tail only).
+    constexpr unsigned NONE = 0xFFFFFFFFu;
+    int prel[NIT], grel[GIT];
+    unsigned pgeo[NIT], ggeo[GIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + 256 * i;
+        prel[i] = 0; pgeo[i] = NONE;
+        if (idx < nitems) {
+            const int p = idx / CPP, ci = idx % CPP;
+            const int tb = fdiv(p, t.div_phw);
+            const int rr = p - tb * (t.PH * t.PW);
+            const int py = fdiv(rr, t.div_pw), px = rr - py * t.PW;
+            prel[i] = tb * a.x_img_pitch + py * a.x_row_pitch + px * a.x_pix_pitch + chunk * CK + ci * (16 / ES);
+            pgeo[i] = (unsigned)tb << 16 | (unsigned)py << 8 | (unsigned)px;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GIT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / GPR, ci = idx % GPR;
+        grel[i] = 0; ggeo[i] = NONE;
+        const int col = n0 + ci * (16 / ES);
+        if (q < t.npx && col + (16 / ES) <= a.dy_cols) {
+            int tb, ty, tx;
+            tile_px(t, q, tb, ty, tx);
+            grel[i] = ((tb * a.OH + ty) * a.OW + tx) * a.dy_ld + col;
+            ggeo[i] = (unsigned)tb << 16 | (unsigned)ty << 8 | (unsigned)tx;
+        }
+    }
+    const bool reflect = a.pad_mode == CVG_PAD_REFLECT;
     u32x4 pv[NIT], gv[GIT];
     auto load_tile = [&](int tl) {
         const int grp = fdiv(tl, a.div_tpg);
         const int r = tl - grp * a.tiles_per_group;
         const int tile_y = fdiv(r, t.div_tx), tile_x = r - tile_y * t.tiles_x;
         const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = grp * t.TB;
+        const int iy0 = y0 + a.off_y, ix0 = x0 + a.off_x;
+        const T* xt = xp + ((ptrdiff_t)b0 * a.x_img_pitch + (ptrdiff_t)iy0 * a.x_row_pitch + (ptrdiff_t)ix0 * a.x_pix_pitch);
+        const T* gt = gp + ((ptrdiff_t)(b0 * a.OH + y0) * a.OW + x0) * a.dy_ld;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + 256 * i;
+            const unsigned g = pgeo[i];
+            const int b = b0 + (int)(g >> 16);
+            int iy = iy0 + (int)((g >> 8) & 255u), ix = ix0 + (int)(g & 255u);
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < nitems) {
-                const int p = idx / CPP, ci = idx % CPP;
-                const int tb = fdiv(p, t.div_phw);
-                const int rr = p - tb * (t.PH * t.PW);
-                const int py = fdiv(rr, t.div_pw), px = rr - py * t.PW;
-                int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
-                const int b = b0 + tb;
-                if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix))
-                    v = *(const u32x4*)(xp + ((size_t)b * a.x_img_pitch + (size_t)(iy * a.x_row_pitch + ix * a.x_pix_pitch) +
-                                              chunk * CK + ci * (16 / ES)));
+            if (g != NONE && b < a.B) {
+                if (reflect) {
+                    const int ry = iy, rx = ix;
+                    pad_xy(CVG_PAD_REFLECT, a.H, a.W, iy, ix);
+                    v = *(const u32x4*)(xt + (prel[i] + (iy - ry) * a.x_row_pitch + (ix - rx) * a.x_pix_pitch));
+                } else if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+                    v = *(const u32x4*)(xt + prel[i]);
+                }
             }
             pv[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < GIT; ++i) {
-            const int idx = tid + 256 * i;
-            const int q = idx / GPR, ci = idx % GPR;
+            const unsigned g = ggeo[i];
+            const int b = b0 + (int)(g >> 16), oy = y0 + (int)((g >> 8) & 255u), ox = x0 + (int)(g & 255u);
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (q < t.npx) {
-                int tb, ty, tx;
-                tile_px(t, q, tb, ty, tx);
-                const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-                const int col = n0 + ci * (16 / ES);
-                if (b < a.B && oy < a.OH && ox < a.OW && col + (16 / ES) <= a.dy_cols)
-                    v = *(const u32x4*)(gp + ((size_t)(b * a.OH + oy) * a.OW + ox) * a.dy_ld + col);
-            }
+            if (g != NONE && b < a.B && oy < a.OH && ox < a.OW) v = *(const u32x4*)(gt + grel[i]);
             gv[i] = v;
         }
     };
