@@ -95,11 +95,11 @@ class KernelTimer:
         for name, fl, a, b, g in self.records:
             d = g.desc
             key = (g.key.replace("encoder.module.", "E.").replace("decoder.module.", "D."), name,
-                   d.B * d.OH * d.OW, d.N, d.ntaps * d.Cin, d.stride, d.oy_off * 2 + d.ox_off)
+                   d.B * d.OH * d.OW, d.N, d.ntaps * d.Cin, d.stride, d.oy_off * 2 + d.ox_off, id(g))
             s = agg.setdefault(key, [fl, 0.0])
             s[1] += a.elapsed_time(b) * 1e-3 / reps
         lines = []
-        for (key, name, M, N, K, st, cls), (fl, t) in agg.items():
+        for (key, name, M, N, K, st, cls, _), (fl, t) in agg.items():
             lines.append("%-28s %-30s M %8d N %5d K %5d s%d c%d  %8.1f us  %7.1f TF" % (
                 key, name, M, N, K, st, cls, t * 1e6, fl / t / 1e12))
         return "\n".join(lines)
@@ -246,19 +246,37 @@ def main():
 
     # ---- roofline of the dominant kernel: event-bracketed launches of two more (eager) steps
     eng.grad_ready = None
+    # (everything on one stream so that a bracket times its launch alone, and behind ~30 ms of
+    # queued matrix products so that the host has enqueued the whole step before its first kernel
+    # starts and the clocks are those of a busy GPU: the events then measure kernels, not launch
+    # gaps or a clock ramp)
+    overlap, eng.overlap = eng.overlap, False
+    wa = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
+    wb = torch.empty_like(wa)
     with KernelTimer(eng) as kt:
         for i in range(2):
             x, labels, eps = batches[i % len(batches)]
+            for _ in range(24):
+                torch.mm(wa, wa, out=wb)
             eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
         agg = kt.summary()
         if args.per_layer:
             print(kt.per_layer(2), file=sys.stderr)
+    eng.overlap = overlap
     name, (fl, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     achieved = fl / t / 1e12
     total_gemm_t = sum(v[1] for v in agg.values()) / 2
+    # HBM-side bytes per launch of that kernel family: PMC counters (FETCH_SIZE doubled as gfx950
+    # needs, plus WRITE_SIZE) from two separate rocprofv3 passes over this same command, reduced by
+    # tools/pmc_traffic.py into profiles/; null when the file is absent or lacks the family
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_%s.json" % args.config)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get(name.replace("(+reduce)", ""), {}).get("bytes")
     roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
                 "all_gemm_ms_per_step": round(total_gemm_t * 1e3, 3),
                 "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3)}
