@@ -157,13 +157,23 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="print a per-layer GEMM table to stderr")
     args = ap.parse_args()
 
+    trace = os.environ.get("CVG_BENCH_TRACE") is not None
+
+    def note(msg):
+        if trace:
+            print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("CVG_BENCH_BACKEND", "nccl")          # "gloo": rehearsal of N > 1 on one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
 
     from cvae_gan_amd.engine import Engine
     from cvae_gan_amd import ddp
@@ -172,45 +182,95 @@ def main():
     if args.batch:
         B = args.batch
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    note("process group up")
     eng = Engine(P, y, z, B, dtype=dtype, seed=0)
     ddp.broadcast_state(eng)
-    sync = None
-    if world > 1:
-        sync = ddp.GradSync(eng.g_arena, ddp.stage_ranges(eng.arena_order, eng.arena_offsets, eng.arena_numel),
-                            ddp.STAGES)
-        eng.grad_ready = sync.on_ready
+    note("state broadcast")
     batches = make_batches(eng, 4, 1234 + rank)
     batch_size_flag = float(B * world)       # the reference divides both losses by --batch_size (global)
     loss_scale = 1.0 / world
 
+    # N > 1: the gradient arena is exchanged in two ranges (it is laid out in the order backward
+    # finishes gradients: the decoder's first), each as one SUM all-reduce on a side stream.  The
+    # decoder's range travels while the encoder's backward pass runs.
+    force_ddp = os.environ.get("CVG_BENCH_FORCE_DDP") is not None      # rehearse the N > 1 control flow on one rank
+    multi = world > 1 or force_ddp
+    ranges = ddp.stage_ranges(eng.arena_order, eng.arena_offsets, eng.arena_numel)
+    dec_lo, dec_hi = ranges["dec"]
+    assert dec_lo == 0, "the decoder's gradients lead the arena"
+    comm = torch.cuda.Stream() if multi else None
+
+    def exchange(lo, hi):
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev)
+            if world > 1 and dist.get_backend() == "nccl":
+                dist.all_reduce(eng.g_arena[lo:hi], op=dist.ReduceOp.SUM)
+            elif world > 1:                  # rehearsal backends reduce a host copy
+                comm.synchronize()
+                host = eng.g_arena[lo:hi].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                eng.g_arena[lo:hi].copy_(host)
+
     def step(i):
         x, labels, eps = batches[i % len(batches)]
         eng.random_mask()
-        if sync:
-            sync.begin_step()
-        eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
-        if sync:
-            sync.finish()
+        if multi:
+            eng.forward_backward_decoder(x, labels, eps, batch_size_flag, loss_scale)
+            exchange(dec_lo, dec_hi)
+            eng.enc_backward(eng.enc["dh"])
+            exchange(dec_hi, eng.arena_numel)
+            torch.cuda.current_stream().wait_stream(comm)
+        else:
+            eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
+        note("step %d enqueued" % i)
         eng.adamw_step(args.lr)
 
-    # A HIP graph of one whole step removes the per-launch host cost (about 400 launches per step).
-    # With the all-reduce in the step (N > 1) the step is launched eagerly.
-    use_graph = (world == 1) and not args.no_graph
-    graph = None
+    # A HIP graph of one whole step removes the per-launch host cost (about 200 launches per step).
+    # With N > 1 the step is three graphs with the gradient exchange between them: [forward +
+    # decoder backward] -> all-reduce of the decoder's gradient range (on a side stream, overlapping
+    # the next graph) -> [encoder backward] -> all-reduce of the encoder's range -> [AdamW].
+    use_graph = not args.no_graph
     for i in range(max(args.warmup, 1)):
         step(i)
     torch.cuda.synchronize()
+    note("eager warm-up done")
     if use_graph:
         x0, l0, e0 = batches[0]
         gx, gl, ge = x0.clone(), l0.clone(), e0.clone()
-        graph = torch.cuda.CUDAGraph()
+        eng.grad_ready = None
         eng.pack_weights(force=True)
         saved = eng.step_count
-        with torch.cuda.graph(graph):
-            eng.random_mask()
-            eng._packed_version = -1
-            eng.forward_backward(gx, gl, ge, batch_size_flag, loss_scale)
-            eng.adamw_step(args.lr)
+        if not multi:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng.random_mask()
+                eng._packed_version = -1
+                eng.forward_backward(gx, gl, ge, batch_size_flag, loss_scale)
+                eng.adamw_step(args.lr)
+
+            def run_graphs():
+                graph.replay()
+        else:
+            g_head, g_enc, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g_head, pool=pool):
+                eng.random_mask()
+                eng._packed_version = -1
+                eng.forward_backward_decoder(gx, gl, ge, batch_size_flag, loss_scale)
+            with torch.cuda.graph(g_enc, pool=pool):
+                eng.enc_backward(eng.enc["dh"])
+            with torch.cuda.graph(g_opt, pool=pool):
+                eng.adamw_step(args.lr)
+
+            def run_graphs():
+                g_head.replay()
+                exchange(dec_lo, dec_hi)
+                g_enc.replay()
+                exchange(dec_hi, eng.arena_numel)
+                torch.cuda.current_stream().wait_stream(comm)
+                g_opt.replay()
         eng.step_count = saved
 
         def step(i):                                    # noqa: F811
@@ -218,9 +278,11 @@ def main():
             gx.copy_(x)
             gl.copy_(labels)
             ge.copy_(eps)
-            graph.replay()
+            run_graphs()
 
         step(0)
+        torch.cuda.synchronize()
+        note("graphs captured and replayed once")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

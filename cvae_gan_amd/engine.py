@@ -709,14 +709,22 @@ class Engine:
         the device.  x f32 NCHW, labels int32, eps f32 [B,z]; the dropout mask is the
         one last set with set_mask()/random_mask().  Gradients land in self.grads;
         self.losses = [KL, LL]."""
+        dec = self.forward_backward_decoder(x, labels, eps, batch_size, loss_scale)
+        self.enc_backward(self.enc["dh"])
+        return dec
+
+    def forward_backward_decoder(self, x, labels, eps, batch_size, loss_scale=1.0):
+        """First part of forward_backward(): forward, losses and the backward pass down to the
+        encoder output (every decoder gradient is final, enc["dh"] holds dL/dh).  A data-parallel
+        driver can start the decoder's gradient exchange here and run enc_backward(enc["dh"])
+        meanwhile."""
         d = self.dec
         h = self.enc_forward(x, labels)
         zin = self.sample(h, eps, batch_size)
         dec = self.dec_forward(zin, d["mask"])
         ops.mse_fwd_bwd(dec, x, d["d_dec"], self.losses[1:2], dec.numel(), batch_size, loss_scale, self.red_ws)
         dzin = self.dec_backward(d["d_dec"], d["mask"])
-        dh = self.sample_backward(dzin, eps, None, None, loss_scale, batch_size)
-        self.enc_backward(dh)
+        self.sample_backward(dzin, eps, None, None, loss_scale, batch_size)
         return dec
 
     def adamw_step(self, lr, betas=ADAM_BETAS, eps=ADAM_EPS, weight_decay=ADAM_WD):
