@@ -34,6 +34,7 @@ struct PatchFwdArgs {
     int y_img_pitch, y_row_pitch, y_pix_pitch, oy_mul, oy_off, ox_mul, ox_off;
     int nchunks, patch_px, patch_bytes;
     int lane_perm;                          // tile rows are 16 pixels wide: use lane_pixel()
+    int row_fast;                           // tile rows hold a multiple of the epilogue's pixels per thread
     TileGeom t;
 };
 
@@ -74,11 +75,13 @@ __device__ __forceinline__ int lane_pixel(int l31, int permute) {
 // forward
 // ======================================================================================
 template <typename T, int WM, int WN, int MI, int NI, int KWT>
-__global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patch_fwd(const PatchFwdArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && NI == 1) ? 2 : 1)     // waves per SIMD
+patch_fwd(const PatchFwdArgs a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int CPP = CK * ES / 16;            // 16-byte pieces per patch pixel
     constexpr int PITCH = CK * ES + 16;          // conflict-free ds_read_b128 across pixels
-    constexpr int NIT = 2 * CPP;                 // patch pieces per thread (patch_px <= 512)
+    constexpr int NT = 64 * WM * WN;             // 4 waves, or 2 (then four workgroups share a CU)
+    constexpr int NIT = NT == 256 ? 2 * CPP : 3 * CPP / 2;       // patch pieces per thread (patch_px <= 512 / 192)
     constexpr int WTM = MI * 32, WTN = NI * 32, BN = WN * WTN;
     constexpr int FRAG = 64 * 8;                 // elements per packed fragment (one wave-load)
     // Taps unrolled per loop body = weight steps in flight per wave: all 9 taps of a 3x3 kernel,
@@ -89,7 +92,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
     // whose 8-pixel x 4-channel windows play the part of 32 "channels")
     constexpr int TU = KWT == 1 ? 7 : ((KWT == 3 && sizeof(T) == 2) ? 9 : KWT);   // f32 fragments are twice as wide: one tap row
     typedef typename Elem<T>::frag frag;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(NT == 256 || NT == 128, "4 or 2 waves");
+    static_assert(NIT * NT >= (NT == 256 ? 512 : 192) * CPP, "patch pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const TileGeom& t = a.t;
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
     const int nitems = a.patch_px * CPP;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NT * i;
         gofs[i] = 0;
         if (idx < nitems) {
             const int p = idx / CPP, ci = idx % CPP;
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
     auto store_patch = [&](char* buf) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NT * i;
             u32x4 v = pv[i];
             if (!((pmask >> i) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
             if (idx < nitems) *(u32x4*)(buf + (idx / CPP) * PITCH + (idx % CPP) * 16) = v;
@@ -238,16 +242,21 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
     constexpr int OP = BN * ES + 16;             // staged row pitch
     const T* __restrict__ resp = (const T*)a.res;
     const T* __restrict__ gatep = (const T*)a.gate;
+    const bool per_pixel = a.cbias != nullptr || resp != nullptr;    // epilogue terms that need the pixel's address
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int q = wm * WTM + mi * 32 + lpx;
-        int tb, ty, tx;
-        tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
-        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-        const bool live = q < t.npx && b < a.B && oy < a.OH && ox < a.OW;
-        const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
-                            (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
-        const float* cb = (a.cbias && live) ? a.cbias + (size_t)a.labels[b] * a.N : nullptr;
+        const int ql = wm * WTM + mi * 32 + lpx;
+        bool live = true;
+        int yoff = 0;
+        const float* cb = nullptr;
+        if (per_pixel) {
+            int tb, ty, tx;
+            tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            live = ql < t.npx && b < a.B && oy < a.OH && ox < a.OW;
+            yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+            if (a.cbias && live) cb = a.cbias + (size_t)a.labels[b] * a.N;
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -256,7 +265,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g4 + j];
-                if (live && n < a.N) {
+                if (n < a.N) {
                     if (a.bias) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
                     }
-                    if (resp) {
+                    if (resp && live) {
                         float r[4];
                         load4<T>(resp + yoff + n, r);
                         if (gatep) {
@@ -278,32 +287,51 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 2 && NI == 1) ? 2 : 1) patc
                         for (int j = 0; j < 4; ++j) v[j] += r[j];
                     }
                 }
-                store4<T>((T*)(smem + (wm * WTM + mi * 32 + lpx) * OP) + nl, v);
+                store4<T>((T*)(smem + ql * OP) + nl, v);
             }
         }
     }
     __syncthreads();
+    // Second half: thread -> (16-byte piece pc of the row, PT consecutive tile pixels).  When the tile
+    // rows hold a multiple of PT pixels (a.row_fast) the PT pixels share one output row: one address
+    // computation, then a fixed step per pixel.
     T* __restrict__ yp = (T*)a.y;
     constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
     constexpr int BMT = WM * WTM;
     constexpr int EPP = 16 / ES;                 // elements per piece
-#pragma unroll
-    for (int i = 0; i < BMT * PPR / 256; ++i) {
-        const int idx = tid + 256 * i;
-        const int q = idx / PPR, pc = idx % PPR;
-        const int n = n0 + pc * EPP;
-        if (q >= t.npx || n >= a.N) continue;
-        int tb, ty, tx;
-        tile_px(t, q, tb, ty, tx);
-        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-        if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
-        const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
-                            (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+    constexpr int PT = BMT * PPR / NT;           // pixels per thread
+    const int pc = tid % PPR, q0 = (tid / PPR) * PT;
+    const int n = n0 + pc * EPP;
+    if (n >= a.N) return;
+    const bool whole = n + EPP <= a.N;           // else N is a multiple of 4: half a 16-bit piece
+    auto put = [&](int q, int yoff) __attribute__((always_inline)) {
         const u32x4 v = *(const u32x4*)(smem + q * OP + pc * 16);
-        if (n + EPP <= a.N) {
-            *(u32x4*)(yp + yoff + n) = v;
-        } else {                                 // N is a multiple of 4: half a 16-bit piece
-            *(unsigned long long*)(yp + yoff + n) = ((unsigned long long)v[1] << 32) | v[0];
+        if (whole) *(u32x4*)(yp + yoff + n) = v;
+        else *(unsigned long long*)(yp + yoff + n) = ((unsigned long long)v[1] << 32) | v[0];
+    };
+    if (a.row_fast) {
+        if (q0 >= t.npx) return;
+        int tb, ty, tx;
+        tile_px(t, q0, tb, ty, tx);
+        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+        if (b >= a.B || oy >= a.OH) return;
+        const int step = a.ox_mul * a.y_pix_pitch;
+        int yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            if (ox + i < a.OW) put(q0 + i, yoff);
+            yoff += step;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int q = q0 + i;
+            if (q >= t.npx) continue;
+            int tb, ty, tx;
+            tile_px(t, q, tb, ty, tx);
+            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
+            put(q, b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch);
         }
     }
 }
@@ -824,7 +852,7 @@ bool patch_eligible(const cvg_conv_desc* d) {
     if (d->x_pix_pitch != d->Cin && !(d->Cin == CK && d->pad_mode == CVG_PAD_ZERO)) return false;   // overlapping windows: one chunk
     if (!((d->KW == 3 && d->ntaps == 9) || (d->KW == 7 && d->ntaps == 49) || (d->KW == 1 && d->ntaps == 7)))
         return false;                                                                        // instantiated kernels
-    if ((int64_t)d->B * d->x_img_pitch >= (1ll << 31)) return false;
+    if ((int64_t)d->B * d->x_img_pitch >= (1ll << 31) || (int64_t)d->B * d->y_img_pitch >= (1ll << 31)) return false;
     return true;
 }
 
@@ -862,7 +890,7 @@ template <typename T, int WM, int WN, int MI, int NI, int KWT>
 int launch_patch_fwd2(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
     if (set_lds(patch_fwd<T, WM, WN, MI, NI, KWT>, p.lds_bytes)) return -1;
     dim3 grid(p.tiles_y * p.tiles_x, ceil_div(a.N, WN * NI * 32), p.groups);
-    patch_fwd<T, WM, WN, MI, NI, KWT><<<grid, 256, p.lds_bytes, s>>>(a);
+    patch_fwd<T, WM, WN, MI, NI, KWT><<<grid, 64 * WM * WN, p.lds_bytes, s>>>(a);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -897,9 +925,15 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
     p.BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
     p.BM = d->N > 64 ? 128 : 256;
+    // 64-channel layers move as many bytes as they multiply: four independent two-wave workgroups per
+    // CU (128 px x 64 ch each) overlap one tile's loads and stores with another's MFMAs better than two
+    // four-wave ones
+    static const bool two_wave = getenv("CVG_PATCH_2W") != nullptr;
+    int max_patch = 512;
+    if (two_wave && d->dtype == CVG_BF16 && d->N > 32 && d->N <= 64) { p.BM = 128; max_patch = 192; }
     static const char* wide = getenv("CVG_PATCH_WIDE");            // experiment: 256 px x 128 ch tiles (bf16)
     if (wide && wide[0] == '1' && d->N > 64 && d->dtype == CVG_BF16) p.BM = 256;
-    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, 512, p.TB, p.TH, p.TW)) return;
+    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
     p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
     p.patch_px = p.TB * p.PH * p.PW;
@@ -932,12 +966,18 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     a.nchunks = p.nchunks; a.patch_px = p.patch_px;
     a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
     a.lane_perm = (p.TW % 16 == 0) ? 1 : 0;
+    {   // pixels per thread in the store phase: BM * (BN * es / 16) / threads
+        const int threads = (p.BN == 64 && p.BM == 128) ? 128 : 256;
+        const int pt = p.BM * (p.BN * es / 16) / threads;
+        a.row_fast = (p.TW % pt == 0) ? 1 : 0;
+    }
     fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
     // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
     if (d->dtype == CVG_BF16) {
         if (p.BN == 128 && p.BM == 256) return launch_patch_fwd<bf16, 2, 2, 4, 2>(p, a, s);
         if (p.BN == 128) return launch_patch_fwd<bf16, 1, 4, 4, 1>(p, a, s);
+        if (p.BN == 64 && p.BM == 128) return launch_patch_fwd<bf16, 1, 2, 4, 1>(p, a, s);
         if (p.BN == 64) return launch_patch_fwd<bf16, 2, 2, 4, 1>(p, a, s);
         return launch_patch_fwd<bf16, 4, 1, 2, 1>(p, a, s);
     }
