@@ -1,0 +1,210 @@
+"""Trainer with the reference's `CVAE` surface (models/cvae.py:23-247) on the fused engine.
+
+Same constructor argument object (starter.py's flags), same attributes, `train()`, `test()`,
+`save()`, `load(pkl=None)`, `model_dir`, and the same checkpoint files: `<dataset>_encoder.pkl` /
+`<dataset>_decoder.pkl` hold state dicts with the reference's keys and layouts (cvae.py:234-235),
+so checkpoints move between the two implementations in both directions.
+
+What differs, on purpose:
+* one engine call per step (forward, both losses, backward, AdamW on the device) instead of
+  module forward + autograd + torch.optim; losses are read back every `log_every` iterations only;
+* the one-hot label planes of cvae.py:129 are never built (labels go in as class indices);
+* eps comes from the device RNG (the reference draws it with numpy on the host, networks.py:30);
+* visdom plots are skipped when visdom is not importable; image grids are written with PIL;
+* multi-GPU is one process per GPU (torchrun) with cvae_gan_amd.ddp, not nn.DataParallel."""
+import os
+import pickle
+import random
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .datasets import make_dataset
+from .engine import Engine, ADAM_BETAS, ADAM_EPS
+
+
+def gaussian(batch_size, n_dim, mean=0.0, var=1.0):
+    """utils.py:157: numpy normal with `var` used as the standard deviation."""
+    return np.random.normal(mean, var, (batch_size, n_dim)).astype(np.float32)
+
+
+def check_folder(path):
+    os.makedirs(path, exist_ok=True)
+    return path
+
+
+def save_image_grid(images, rows, cols, path):
+    """images [N,H,W,3] in [-1,1] (BGR, as the network sees them) -> one PNG grid (utils.py:18-53)."""
+    from PIL import Image
+    n, h, w, _ = images.shape
+    grid = np.zeros((rows * h, cols * w, 3), dtype=np.float32)
+    for i in range(min(n, rows * cols)):
+        r, c = i // cols, i % cols
+        grid[r * h:(r + 1) * h, c * w:(c + 1) * w] = images[i]
+    rgb = ((grid[:, :, ::-1] + 1.0) * 127.5).clip(0, 255).astype(np.uint8)
+    Image.fromarray(rgb).save(path)
+
+
+class CVAE(object):
+    def __init__(self, args):
+        self.epoch = args.epoch
+        self.sample_num = 10
+        self.batch_size = args.batch_size
+        self.save_dir = args.save_dir
+        self.result_dir = args.result_dir
+        self.dataset = args.dataset
+        self.device = torch.device(getattr(args, "device", "cuda"))
+        self.y_dim, self.z_dim, self.pix_dim = args.y_dim, args.z_dim, args.pix_dim
+        self.lr = args.lrG
+        self.log_every = getattr(args, "log_every", 3)           # cvae.py:159
+        self.max_iters = getattr(args, "max_iters", 0)           # 0: whole epochs
+        dtype = getattr(args, "dtype", "bf16")
+        self.dtype = torch.float32 if dtype in ("f32", torch.float32) else torch.bfloat16
+
+        self.train_data, self.synthetic = make_dataset(args.data_dir, args.dataset, args.pix_dim, args.y_dim,
+                                                       max_size=args.data_size)
+        if self.synthetic:
+            print("data directory %r has no %r listing: using the synthetic stand-in"
+                  % (args.data_dir, args.dataset))
+        print("Trainset: %d \n" % len(self.train_data))
+        self.trainset_loader = DataLoader(dataset=self.train_data, batch_size=args.batch_size, drop_last=True,
+                                          shuffle=True, num_workers=getattr(args, "worker", 0), pin_memory=True)
+
+        self.engine = Engine(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
+                             device=self.device, seed=getattr(args, "seed", 0))
+        self._sample_engine = None
+        if getattr(args, "resume", False):
+            try:
+                self.load()
+            except FileNotFoundError:
+                print("no checkpoint to resume from in", os.path.join(self.save_dir, self.model_dir))
+        if getattr(args, "testmode", False):
+            self.load(args.pkl if getattr(args, "pkl", "") else None)
+
+        # fixed noise & condition (cvae.py:77-90): sample_num latent rows, each repeated for every class
+        n = self.sample_num * self.y_dim
+        self.sample_z_ = torch.zeros((n, self.z_dim))
+        for i in range(self.sample_num):
+            row = torch.from_numpy(gaussian(1, self.z_dim, mean=random.uniform(-0.5, 0.5), var=random.uniform(0.5, 1.5)))
+            self.sample_z_[i * self.y_dim:(i + 1) * self.y_dim] = row
+        self.sample_y_ = torch.zeros((n, self.y_dim))
+        self.sample_y_[torch.arange(n), torch.arange(n) % self.y_dim] = 1
+        self.train_hist = {}
+
+    # ------------------------------------------------------------------ checkpoints
+    @property
+    def model_dir(self):
+        return "VAE_data_{}_pix_{}_batch_{}_embed_{}".format(self.dataset, self.pix_dim, self.batch_size, self.z_dim)
+
+    def save(self):
+        save_dir = check_folder(os.path.join(self.save_dir, self.model_dir))
+        torch.save(self.engine.state_dict("encoder"), os.path.join(save_dir, self.dataset + "_encoder.pkl"))
+        torch.save(self.engine.state_dict("decoder"), os.path.join(save_dir, self.dataset + "_decoder.pkl"))
+        with open(os.path.join(save_dir, self.dataset + "_history.pkl"), "wb") as f:
+            pickle.dump(self.train_hist, f)
+
+    def load(self, pkl=None):
+        base = os.path.join(self.save_dir, self.model_dir, self.dataset) if pkl is None else pkl
+        for half in ("encoder", "decoder"):
+            sd = torch.load(base + "_%s.pkl" % half, map_location="cpu", weights_only=True)
+            self.engine.load_state(sd)
+
+    # ------------------------------------------------------------------ training
+    def _to_device(self, imgs, labels):
+        x = imgs.to(self.device, non_blocking=True).float().contiguous()
+        cls = torch.max(labels, 1)[1].to(torch.int32).to(self.device, non_blocking=True)
+        return x, cls
+
+    def train(self):
+        hist = self.train_hist = {"VAE_loss": [], "KL_loss": [], "LL_loss": [], "per_epoch_time": [], "total_time": []}
+        eng = self.engine
+        eng.training = True
+        print("training start!!")
+        eps = torch.empty(self.batch_size, self.z_dim, device=self.device)
+        start_time = time.time()
+        iters = 0
+        for epoch in range(self.epoch):
+            epoch_start = time.time()
+            it = -1
+            for it, (imgs, labels) in enumerate(self.trainset_loader):
+                x, cls = self._to_device(imgs, labels)
+                eps.normal_()
+                eng.random_mask()
+                eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
+                iters += 1
+                if (it + 1) % self.log_every == 0:
+                    l = eng.read_losses()
+                    hist["VAE_loss"].append(l["VAE"])
+                    hist["KL_loss"].append(l["KL"])
+                    hist["LL_loss"].append(l["LL"])
+                    print("Epoch: [%2d] [%4d/%4d] time: %4.4f VAE_loss: %.8f KL_loss: %.8f LL_loss: %.8f" %
+                          (epoch + 1, it + 1, len(self.train_data) // self.batch_size, time.time() - start_time,
+                           l["VAE"], l["KL"], l["LL"]))
+                if self.max_iters and iters >= self.max_iters:
+                    break
+            samples = self.sample_grid()
+            out_dir = check_folder(os.path.join(self.result_dir, self.model_dir))
+            save_image_grid(samples, self.sample_num, self.y_dim,
+                            os.path.join(out_dir, self.dataset + "_train_{:02d}_{:04d}.png".format(epoch, it + 1)))
+            if epoch % 10 == 0:
+                self.save()
+            hist["per_epoch_time"].append(time.time() - epoch_start)
+            if self.max_iters and iters >= self.max_iters:
+                break
+        hist["total_time"].append(time.time() - start_time)
+        print("Avg one epoch time: %.2f, total %d epochs time: %.2f" %
+              (float(np.mean(hist["per_epoch_time"])), self.epoch, hist["total_time"][0]))
+        print("Training finish!... save training results")
+        self.save()
+
+    # ------------------------------------------------------------------ inference
+    def sample_grid(self):
+        """Eval-mode decoder on the fixed latents, every class per latent row (cvae.py:167-178).
+        Returns [sample_num * y_dim, P, P, 3] float32 in [-1, 1]."""
+        n = self.sample_num * self.y_dim
+        if self._sample_engine is None:
+            self._sample_engine = Engine(self.pix_dim, self.y_dim, self.z_dim, n, dtype=self.dtype,
+                                         device=self.device, share=self.engine)
+        se = self._sample_engine
+        se.training = False
+        out = se.decode(self.sample_z_.to(self.device), self.sample_y_.to(self.device))
+        return out.detach().float().cpu().numpy().transpose(0, 2, 3, 1)
+
+    def reconstruct(self, imgs, labels, eps=None):
+        """Eval-mode encoder + decoder (cvae.py:209-213).  imgs [B,3,P,P], labels one-hot [B,y]."""
+        x, cls = self._to_device(imgs, labels)
+        eng = self.engine
+        assert x.shape[0] == eng.B, "batch size is fixed by --batch_size"
+        if eps is None:
+            eps = torch.randn(eng.B, self.z_dim, device=self.device)
+        was, eng.training = eng.training, False
+        try:
+            out = eng.reconstruct(x, cls, eps.to(self.device))
+        finally:
+            eng.training = was
+        return out
+
+    def test(self):
+        iter_num = 10
+        ins, outs = [], []
+        for it, (imgs, labels) in enumerate(self.trainset_loader):
+            out = self.reconstruct(imgs, labels)
+            outs.append(out.detach().float().cpu().numpy().transpose(0, 2, 3, 1))
+            ins.append(imgs.numpy().transpose(0, 2, 3, 1))
+            if it + 1 >= iter_num:
+                break
+        if not ins:
+            raise RuntimeError("the dataset is smaller than one batch")
+        # rows alternate inputs and reconstructions, one batch per row pair (utils.py:26-33)
+        cols = min(self.batch_size, 16)
+        rows = []
+        for a, b in zip(ins, outs):
+            rows.append(a[:cols])
+            rows.append(b[:cols])
+        grid = np.concatenate(rows, 0)
+        out_dir = check_folder(os.path.join(self.result_dir, self.model_dir))
+        path = os.path.join(out_dir, self.dataset + "_test_{:03d}.png".format(iter_num))
+        save_image_grid(grid, len(rows), cols, path)
+        return path

@@ -727,6 +727,19 @@ class Engine:
         self.sample_backward(dzin, eps, None, None, loss_scale, batch_size)
         return dec
 
+    # ------------------------------------------------------------------ inference
+    def reconstruct(self, x, labels, eps):
+        """Forward only: decoder(sample(encoder(x, labels)), labels) (models/cvae.py:212).  With
+        self.training False, BatchNorm uses its running statistics and Dropout is the identity."""
+        h = self.enc_forward(x, labels)
+        zin = self.sample(h, eps, 1.0)
+        return self.dec_forward(zin, self.dec["mask"])
+
+    def decode(self, z, y_vec):
+        """Decoder only, from f32 latents [B,z] and one-hot labels [B,y] (models/cvae.py:171)."""
+        zin = self.set_decoder_input(z, y_vec)
+        return self.dec_forward(zin, self.dec["mask"])
+
     def adamw_step(self, lr, betas=ADAM_BETAS, eps=ADAM_EPS, weight_decay=ADAM_WD):
         self.step_count += 1
         ops.adamw_dev(self.p_arena, self.g_arena, self.m_arena, self.v_arena, self.arena_numel, lr, betas[0],
