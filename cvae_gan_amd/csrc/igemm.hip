@@ -299,7 +299,7 @@ __global__ void splitk_finish(const float* __restrict__ ws, T* __restrict__ y, c
 // weight-gradient kernel
 // ================================================================================
 template <typename T, int BNW, int BKW, int WN, int WK>
-__global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
+__global__ void __launch_bounds__(256, 2) igemm_wgrad(const WgradArgs a) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int BMS = 128 / (int)sizeof(T);                 // pixels per step: 64 bf16 / 32 f32
     constexpr int PG = BNW * (int)sizeof(T) + 64, PA = BKW * (int)sizeof(T) + 64;
@@ -310,7 +310,9 @@ __global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
     constexpr int STAGE = BMS * (PG + PA);
     typedef typename Elem<T>::frag frag;
     static_assert(WN * WK == 4 && PGN >= 1 && PAN >= 1, "tile");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    // one LDS stage (the next step waits in registers): 41 KB, so three workgroups share a CU and
+    // cover each other's barriers
+    __shared__ __attribute__((aligned(16))) char smem[STAGE];
 
     const Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,8 +363,8 @@ __global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
             rav[i] = v;
         }
     };
-    auto store_tile = [&](int buf) {
-        char* Gs = smem + buf * STAGE;
+    auto store_tile = [&]() {
+        char* Gs = smem;
         char* As = Gs + BMS * PG;
 #pragma unroll
         for (int i = 0; i < PGN; ++i) *(u32x4*)(Gs + (rg0 + RG * i) * PG + ccg * 16) = rgv[i];
@@ -378,16 +380,13 @@ __global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][ki][r] = 0.f;
 
-    if (st_beg < st_end) {
-        load_tile(st_beg);
-        store_tile(0);
-    }
-    __syncthreads();
+    if (st_beg < st_end) load_tile(st_beg);
     for (int st = st_beg; st < st_end; ++st) {
-        const int buf = (st - st_beg) & 1;
-        const bool more = st + 1 < st_end;
-        if (more) load_tile(st + 1);
-        const char* Gs = smem + buf * STAGE;
+        __syncthreads();                     // everyone is done reading the previous step
+        store_tile();
+        __syncthreads();
+        if (st + 1 < st_end) load_tile(st + 1);
+        const char* Gs = smem;
         const char* As = Gs + BMS * PG;
 #pragma unroll
         for (int sub = 0; sub < BMS / 16; ++sub) {
@@ -401,8 +400,6 @@ __global__ void __launch_bounds__(256) igemm_wgrad(const WgradArgs a) {
 #pragma unroll
                 for (int ki = 0; ki < KI; ++ki) mma32(acc[ni][ki], gf[ni], af[ki]);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
     }
 
     // partials: ws[z][n][k], D[row = n][col = k]
