@@ -76,7 +76,10 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
     constexpr int STAGE = (BM + BN) * PITCH;
     typedef typename Elem<T>::frag frag;
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    // one LDS stage (the next k-step waits in registers): three or four workgroups share a CU and
+    // cover each other's barriers
+    constexpr int OUT_BYTES = BM * (BN * (int)sizeof(T) + 16);   // the staged output tile reuses the buffer
+    __shared__ __attribute__((aligned(16))) char smem[STAGE > OUT_BYTES ? STAGE : OUT_BYTES];
 
     const Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,8 +131,8 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
         for (int i = 0; i < BR; ++i)
             rb[i] = *(const u32x4*)(wp + wrow + (size_t)(32 * i) * a.w_ld + (ks * BK + cc * VEC));
     };
-    auto store_tile = [&](int buf) {
-        char* As = smem + buf * STAGE;
+    auto store_tile = [&]() {
+        char* As = smem;
         char* Ws = As + BM * PITCH;
 #pragma unroll
         for (int i = 0; i < AR; ++i) *(u32x4*)(As + (r0 + 32 * i) * PITCH + cc * 16) = ra[i];
@@ -148,16 +151,13 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
     const int ks_beg = zsplit * a.nk_per_split;
     const int ks_end = min(a.nk_total, ks_beg + a.nk_per_split);
 
-    if (ks_beg < ks_end) {
-        load_tile(ks_beg);
-        store_tile(0);
-    }
-    __syncthreads();
+    if (ks_beg < ks_end) load_tile(ks_beg);
     for (int ks = ks_beg; ks < ks_end; ++ks) {
-        const int buf = (ks - ks_beg) & 1;
-        const bool more = ks + 1 < ks_end;
-        if (more) load_tile(ks + 1);
-        const char* As = smem + buf * STAGE;
+        __syncthreads();                         // everyone is done reading the previous k-step
+        store_tile();
+        __syncthreads();
+        if (ks + 1 < ks_end) load_tile(ks + 1);
+        const char* As = smem;
         const char* Ws = As + BM * PITCH;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -174,9 +174,8 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wf[ni], xf[mi]);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
     }
+    __syncthreads();
 
     // ---- epilogue: D[row = n][col = m]; lane owns pixel column l31, 4 consecutive n per register group.
     // Split-K partials go straight to the workspace; final values are staged in LDS (free after the
@@ -186,7 +185,7 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
     const T* __restrict__ gatep = (const T*)a.gate;
     constexpr int ES = (int)sizeof(T);
     constexpr int OP = BN * ES + 16;             // staged row pitch
-    static_assert(BM * OP <= 2 * STAGE, "output tile must fit the operand buffers");
+    static_assert(BM * OP == OUT_BYTES, "staged tile size");
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int ml = wm * WTM + mi * 32 + l31, m = m0 + ml;
