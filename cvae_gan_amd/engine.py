@@ -591,11 +591,7 @@ class Engine:
             p, M, C = blk["prefix"], blk["M"], blk["cin"]
             with self._branch():
                 self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
-            if blk["cin"] > 64:
-                blk["dgd_group"].run(blk["d_out"], blk["d_r"])
-            else:                                   # narrow outputs: the classes run faster one after another
-                for g in blk["dgd"]:
-                    self._fwd(g, blk["d_out"], blk["d_r"])
+            blk["dgd_group"].run(blk["d_out"], blk["d_r"])
             self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
             with self._branch():
                 self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
