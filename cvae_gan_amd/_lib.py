@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
 
 class WMap(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "nd", "na", "nb", "kd", "ka", "kb", "n_valid", "kc_valid", "ntaps", "tap_mode")] + \
+        "nd", "na", "nb", "kd", "ka", "kb", "n_valid", "kc_valid", "ntaps", "tap_mode", "nr_valid", "reserved")] + \
         [("tap_table", C.c_int16 * 64)]
 
 
@@ -54,6 +54,7 @@ def _load():
         "cvg_conv_fwd_kernel": (C.c_char_p, [P(ConvDesc)]),
         "cvg_conv_wgrad_kernel": (C.c_char_p, [P(ConvDesc)]),
         "cvg_conv_wgrad": (C.c_int, [P(ConvDesc), vp, vp, i32, P(WMap), vp, i32, vp, sz, vp]),
+        "cvg_conv_wgrad_strided": (C.c_int, [P(ConvDesc), vp, vp, P(WMap), vp, i32, vp, sz, vp]),
         "cvg_weight_pack": (C.c_int, [P(ConvDesc), P(WMap), vp, vp, vp]),
         "cvg_weight_pack_job": (C.c_int, [P(ConvDesc), P(WMap), vp, vp, i32, P(PackJob)]),
         "cvg_weight_pack_batch": (C.c_int, [vp, i32, i32, vp]),

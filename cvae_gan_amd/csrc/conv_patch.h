@@ -35,5 +35,7 @@ struct PatchWgradPlan {
     size_t lds_bytes, ws_bytes;
 };
 void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p);
+// dY[b][oy][ox][n] at dy + b*dy_img_pitch + oy*dy_row_pitch + ox*dy_ld + n, n < dy_cols readable.
 int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const void* x, const void* dy, int dy_ld,
+                       int dy_img_pitch, int dy_row_pitch, int dy_cols,
                        const cvg_wmap* map, float* grad, int accumulate, float* ws, hipStream_t s);

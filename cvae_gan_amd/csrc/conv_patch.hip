@@ -361,7 +361,8 @@ struct PatchWgradArgs {
     const void* x; const void* dy; float* ws;
     int B, H, W, Cin, x_img_pitch, x_row_pitch, x_pix_pitch;
     int off_y, off_x, pad_mode, KW, T;
-    int OH, OW, dy_ld, dy_cols;
+    int OH, OW, dy_cols;                       // dY[b][oy][ox][n]: pitches below, n < dy_cols readable
+    int dy_img_pitch, dy_row_pitch, dy_pix_pitch;
     int patch_px, ntiles, tiles_per_split, tiles_per_group;
     int n_rows, k_ld;
     int nchunks, nchunks_ntiles, xcd_remap;
@@ -499,7 +500,7 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
         if (q < t.npx && col + (16 / ES) <= a.dy_cols) {
             int tb, ty, tx;
             tile_px(t, q, tb, ty, tx);
-            grel[i] = ((tb * a.OH + ty) * a.OW + tx) * a.dy_ld + col;
+            grel[i] = tb * a.dy_img_pitch + ty * a.dy_row_pitch + tx * a.dy_pix_pitch + col;
             ggeo[i] = (unsigned)tb << 16 | (unsigned)ty << 8 | (unsigned)tx;
         }
     }
@@ -512,7 +513,7 @@ __global__ void __launch_bounds__(256, 1) patch_wgrad(const PatchWgradArgs a) {
         const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = grp * t.TB;
         const int iy0 = y0 + a.off_y, ix0 = x0 + a.off_x;
         const T* xt = xp + ((ptrdiff_t)b0 * a.x_img_pitch + (ptrdiff_t)iy0 * a.x_row_pitch + (ptrdiff_t)ix0 * a.x_pix_pitch);
-        const T* gt = gp + ((ptrdiff_t)(b0 * a.OH + y0) * a.OW + x0) * a.dy_ld;
+        const T* gt = gp + ((ptrdiff_t)b0 * a.dy_img_pitch + (ptrdiff_t)y0 * a.dy_row_pitch + (ptrdiff_t)x0 * a.dy_pix_pitch);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const unsigned g = pgeo[i];
@@ -709,7 +710,7 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
         if (q < t.npx && col + (16 / ES) <= a.dy_cols) {
             int tb, ty, tx;
             tile_px(t, q, tb, ty, tx);
-            grel[i] = ((tb * a.OH + ty) * a.OW + tx) * a.dy_ld + col;
+            grel[i] = tb * a.dy_img_pitch + ty * a.dy_row_pitch + tx * a.dy_pix_pitch + col;
             ggeo[i] = (unsigned)tb << 16 | (unsigned)ty << 8 | (unsigned)tx;
         }
     }
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
         const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = grp * t.TB;
         const int iy0 = y0 + a.off_y, ix0 = x0 + a.off_x;
         const T* xt = xp + ((ptrdiff_t)b0 * a.x_img_pitch + (ptrdiff_t)iy0 * a.x_row_pitch + (ptrdiff_t)ix0 * a.x_pix_pitch);
-        const T* gt = gp + ((ptrdiff_t)(b0 * a.OH + y0) * a.OW + x0) * a.dy_ld;
+        const T* gt = gp + ((ptrdiff_t)b0 * a.dy_img_pitch + (ptrdiff_t)y0 * a.dy_row_pitch + (ptrdiff_t)x0 * a.dy_pix_pitch);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const unsigned g = pgeo[i];
@@ -1068,6 +1069,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
 }
 
 int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const void* x, const void* dy, int dy_ld,
+                       int dy_img_pitch, int dy_row_pitch, int dy_cols,
                        const cvg_wmap* map, float* grad, int accumulate, float* ws, hipStream_t s) {
     PatchWgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws;
@@ -1075,7 +1077,8 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     // overlapping windows (pixel pitch < Cin): the last whole window starts Cin/pitch - 1 pixels before the row end
     if (d->x_pix_pitch != d->Cin) a.W = d->W - d->Cin / d->x_pix_pitch + 1;
     a.off_y = d->off_y; a.off_x = d->off_x; a.pad_mode = d->pad_mode; a.KW = p.KW; a.T = p.T;
-    a.OH = d->OH; a.OW = d->OW; a.dy_ld = dy_ld; a.dy_cols = dy_ld;
+    a.OH = d->OH; a.OW = d->OW; a.dy_cols = dy_cols;
+    a.dy_pix_pitch = dy_ld; a.dy_row_pitch = dy_row_pitch; a.dy_img_pitch = dy_img_pitch;
     a.patch_px = p.patch_px; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     a.tiles_per_group = p.tiles_y * p.tiles_x;
     a.n_rows = p.n_tiles * p.BNW; a.k_ld = p.T * d->Cin;

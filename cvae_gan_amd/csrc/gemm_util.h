@@ -43,6 +43,7 @@ __device__ __forceinline__ int wmap_index(const cvg_wmap& m, int n, int k) {
     else if (m.tap_mode == 2) t = m.tap_table[j];
     if (t < 0) return -1;
     const int nq = n / m.nd, nr = n - nq * m.nd;
+    if (m.nr_valid > 0 && nr >= m.nr_valid) return -1;
     return nq * m.na + nr * m.nb + t * m.ka + c * m.kb;
 }
 

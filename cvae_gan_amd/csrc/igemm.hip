@@ -674,6 +674,21 @@ int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x, con
                                  : launch_fwd_group<float>(n, m.a[0].g.M, d0->N, m, s);
 }
 
+int cvg_conv_wgrad_strided(const cvg_conv_desc* d, const void* x, const void* dy, const cvg_wmap* map, float* grad,
+                           int32_t accumulate, void* ws, size_t ws_bytes, cvg_stream stream) {
+    CVG_CHECK(d && x && dy && map && grad && ws, "conv_wgrad_strided: null tensor");
+    CVG_CHECK(map->kd > 0 && map->nd > 0, "conv_wgrad_strided: bad map");
+    CVG_CHECK(d->y_pix_pitch % 4 == 0 && d->y_row_pitch % 4 == 0 && d->y_img_pitch % 4 == 0 && d->N % 8 == 0,
+              "conv_wgrad_strided: dY pitches must keep 8-byte alignment, N a multiple of 8");
+    PatchWgradPlan wp;
+    patch_wgrad_plan(d, wp);
+    CVG_CHECK(patch_enabled() && wp.ok, "conv_wgrad_strided: only the patch-staged kernels read strided dY");
+    CVG_CHECK((int64_t)d->B * d->y_img_pitch < (1ll << 31), "conv_wgrad_strided: dY too large for 32-bit offsets");
+    CVG_CHECK(ws_bytes >= wp.ws_bytes, "conv_wgrad_strided: workspace too small");
+    return patch_wgrad_launch(d, wp, x, dy, d->y_pix_pitch, d->y_img_pitch, d->y_row_pitch, d->N, map, grad, accumulate,
+                              (float*)ws, (hipStream_t)stream);
+}
+
 const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {
     if (patch_enabled()) {
         PatchPlan pp;
@@ -714,7 +729,8 @@ int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_
         patch_wgrad_plan(d, wp);
         if (wp.ok) {
             CVG_CHECK(ws_bytes >= wp.ws_bytes, "conv_wgrad: workspace too small");
-            return patch_wgrad_launch(d, wp, x, dy, dy_ld, map, grad, accumulate, (float*)ws, (hipStream_t)stream);
+            return patch_wgrad_launch(d, wp, x, dy, dy_ld, d->OH * d->OW * dy_ld, d->OW * dy_ld, dy_ld, map, grad,
+                                      accumulate, (float*)ws, (hipStream_t)stream);
         }
     }
     WgradPlan p = plan_wgrad(d, a.g.M);

@@ -193,8 +193,9 @@ def _desc(dtype, B, H, W, Cin, OH, OW, N, KW, ntaps, stride=1, tstep=(1, 1), off
     return d
 
 
-def _wmap(nd, na, nb, kd, ka, kb, n_valid, kc_valid, ntaps, tap_mode=0, table=None):
+def _wmap(nd, na, nb, kd, ka, kb, n_valid, kc_valid, ntaps, tap_mode=0, table=None, nr_valid=0):
     m = WMap()
+    m.nr_valid = nr_valid
     m.nd, m.na, m.nb, m.kd, m.ka, m.kb = nd, na, nb, kd, ka, kb
     m.n_valid, m.kc_valid, m.ntaps, m.tap_mode = n_valid, kc_valid, ntaps, tap_mode
     if table is not None:
@@ -232,6 +233,7 @@ class Engine:
         self._gemms, self._ws_bytes = [], 0
         self.overlap = os.environ.get("CVG_NO_OVERLAP") is None     # A/B switch for benchmarking
         self._side, self._side_dirty = None, False
+        self._wgrad_descs = []          # weight-gradient-only descriptors (workspace sizing)
         self._pack_batch = None
         self.step_count = 0
         self.training = True
@@ -458,6 +460,21 @@ class Engine:
         d["tail_dg"] = _Gemm(self, _desc(T, B, P + 12, P + 14, 32, P + 6, P + 6, ngf, 1, 7, x_pix=4),
                              _wmap(1, 49, 0, 4, 1, ngf * 49, ngf, 3, 56, tap_mode=2, table=table), key + "weight")
         d["dpre_win"] = self._t(B, P + 12, P + 14, 4)
+        # weight gradient of the tail through the same windows: with x' = x + kw,
+        #   dW[n][c][kh][kw] = sum_{y,x'} win[y][x'][(6 - kw, n)] * Xpad[y + kh][x'][c]
+        # i.e. 7 row taps over the reflection-padded input and 32 "output channels" (window pixel,
+        # n) instead of 49 taps with 3 real output rows out of 32: a seventh of the MFMA work.
+        # dY = rows 6.. of the window image, read through the descriptor's output pitches.
+        Wp = P + 14
+        d["tail_wg_desc"] = _desc(T, B, P, P, ngf, P, P + 6, 32, 1, 7, off=(-3, -3), pad_mode=PAD_REFLECT,
+                                  y_pix=4, y_row=Wp * 4, y_img=(P + 12) * Wp * 4)
+        d["tail_wg_map"] = _wmap(4, -1, ngf * 49, ngf, 1, 49, 28, ngf, 7, tap_mode=2,
+                                 table=[kh * 7 + 6 for kh in range(7)], nr_valid=3)
+        d["tail_wg_dy"] = d["dpre_win"][:, 6:]
+        # (narrow networks, ngf < 32, keep the 49-tap form on the gather kernel)
+        d["tail_wg_windows"] = ops.conv_wgrad_kernel(d["tail_wg_desc"]).startswith("patch_wgrad")
+        if d["tail_wg_windows"]:
+            self._wgrad_descs.append(d["tail_wg_desc"])
         d["tail_bias"] = self._f(4)
         d["pre"] = self._t(B * P * P, 4)
         d["dpre"] = self._t(B * P * P, 8)
@@ -477,6 +494,8 @@ class Engine:
         wg = 0
         for g in self._gemms:
             wg = max(wg, ops.conv_wgrad_workspace(g.desc))
+        for desc in self._wgrad_descs:
+            wg = max(wg, ops.conv_wgrad_workspace(desc))
         self.ws = torch.zeros(max(wg, self._ws_bytes, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
         max_c = max(self.ngf * 8, self.dec["nout"], 4 * self.z, self.dec["F8"])
         self.red_ws = torch.zeros(2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
@@ -655,7 +674,11 @@ class Engine:
         ops.tanh_bwd(d_dec, d["dec"], d["dpre"], B, P, d["dpre_win"])
         last = d["ups"][-1]
         with self._branch():
-            self._wgrad(d["tail"], last["y"], d["dpre"], 8)
+            if d["tail_wg_windows"]:
+                ops.conv_wgrad_strided(d["tail_wg_desc"], last["y"], d["tail_wg_dy"], d["tail_wg_map"],
+                                       self.grads[d["tail_key"] + "weight"], self.ws_side)
+            else:
+                self._wgrad(d["tail"], last["y"], d["dpre"], 8)
             ops.colsum(d["dpre"], B * P * P, 8, 8, d["bgrad8"], self.red_ws_side)
             ops.permute_f32(d["bgrad8"], self.grads[d["tail_key"] + "bias"], 3)
         self._fwd(d["tail_dg"], d["dpre_win"], d["dxp"])

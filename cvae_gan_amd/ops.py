@@ -64,6 +64,21 @@ def conv_wgrad_workspace(desc):
     return int(lib.cvg_conv_wgrad_workspace(C.byref(desc)))
 
 
+def conv_fwd_kernel(desc):
+    """Name of the kernel family the library picks for this descriptor."""
+    return lib.cvg_conv_fwd_kernel(C.byref(desc)).decode()
+
+
+def conv_wgrad_kernel(desc):
+    return lib.cvg_conv_wgrad_kernel(C.byref(desc)).decode()
+
+
+def conv_wgrad_strided(desc, x, dy, wmap, grad, ws, accumulate=False):
+    """dy addressed through desc.y_*_pitch (see include/cvaegan.h)."""
+    check(lib.cvg_conv_wgrad_strided(C.byref(desc), ptr(x), ptr(dy), C.byref(wmap), ptr(grad), int(accumulate),
+                                     ptr(ws), ws.numel() * ws.element_size(), stream()))
+
+
 def weight_pack(desc, wmap, canonical, packed):
     assert packed.numel() >= desc.w_rows * desc.w_ld and dt(packed) == desc.dtype
     check(lib.cvg_weight_pack(C.byref(desc), C.byref(wmap), ptr(canonical), ptr(packed), stream()))

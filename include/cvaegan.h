@@ -98,9 +98,11 @@ typedef struct cvg_wmap {
     /* canonical index of GEMM-layout element (n, k):
      *   (n / nd)*na + (n % nd)*nb + tap(k / kd)*ka + (k % kd)*kb
      * tap(j) = j (tap_mode 0), ntaps-1-j (1) or tap_table[j] (2; -1 = structural zero).
-     * Elements with n >= n_valid, (k % kd) >= kc_valid or k / kd >= ntaps are zero. */
+     * Elements with n >= n_valid, (k % kd) >= kc_valid or k / kd >= ntaps are zero, and so are
+     * those with (n % nd) >= nr_valid when nr_valid > 0 (padding rows inside every group of nd). */
     int32_t nd, na, nb, kd, ka, kb;
     int32_t n_valid, kc_valid, ntaps, tap_mode;
+    int32_t nr_valid, reserved;
     int16_t tap_table[64];
 } cvg_wmap;
 
@@ -111,6 +113,16 @@ const char* cvg_conv_wgrad_kernel(const cvg_conv_desc* d);
 int    cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_t dy_ld,
                       const cvg_wmap* map, float* grad, int32_t accumulate,
                       void* ws, size_t ws_bytes, cvg_stream s);
+
+/* The same with dY addressed through the descriptor's output pitches:
+ * dY[b][oy][ox][n] = dy[b*y_img_pitch + oy*y_row_pitch + ox*y_pix_pitch + n], n < N.  A pixel
+ * pitch below N makes the N columns an overlapping window over neighbouring pixels: with the
+ * tail's dpre stored as 4-channel pixels, 8-pixel windows turn the 7x7 tail's weight gradient
+ * (nn.Conv2d(64, 3, 7), networks.py:146-148) into 7 row taps with 32 "output channels" (kw, n).
+ * Only descriptors the patch-staged kernels accept.                                        */
+int    cvg_conv_wgrad_strided(const cvg_conv_desc* d, const void* x, const void* dy,
+                              const cvg_wmap* map, float* grad, int32_t accumulate,
+                              void* ws, size_t ws_bytes, cvg_stream s);
 
 /* Canonical f32 weights -> the layout the kernels chosen for `d` consume, in d->dtype:
  * row-major [w_rows][w_ld] (k = tap*Cin + c, zero padded) for the gather kernel, MFMA

@@ -157,3 +157,35 @@ def test_linear_split_k(dtype, M, K, N):
     yr = torch.zeros(M, N, dtype=dtype, device="cuda")
     ops.conv_fwd(d, x.to(dtype).cuda(), pack(ops, wm, w, d, dtype), yr, bias=b.cuda(), ws=ws_for(ops, d))
     assert relmax(yr.float().cpu(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,P,ngf", [(3, 16, 32), (2, 32, 64)])
+def test_tail_weight_gradient_through_windows(dtype, B, P, ngf):
+    """cvg_conv_wgrad_strided: the 7x7, 3-output-channel tail's weight gradient as 7 row taps with
+    the (window pixel, channel) pairs of a zero-padded 4-channel dpre image as output channels,
+    against torch's conv2d weight gradient (ReflectionPad2d(3) + Conv2d(ngf, 3, 7), networks.py:146)."""
+    ops, _desc, _wmap = _mods()
+    from cvae_gan_amd._lib import PAD_REFLECT
+    g = torch.Generator().manual_seed(B * 100 + P + ngf)
+    x = torch.randn(B, ngf, P, P, generator=g)
+    dpre = torch.randn(B, 3, P, P, generator=g)
+    if dtype == torch.bfloat16:
+        x, dpre = x.bfloat16().float(), dpre.bfloat16().float()
+    w = torch.zeros(3, ngf, 7, 7, requires_grad=True)
+    F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w).backward(dpre)
+    ref = w.grad
+    # window image [B][P+12][P+14][4], interior at (6, 6)
+    win = torch.zeros(B, P + 12, P + 14, 4)
+    win[:, 6:6 + P, 6:6 + P, :3] = dpre.permute(0, 2, 3, 1)
+    win = win.to(dtype).cuda()
+    Wp = P + 14
+    desc = _desc(dtype, B, P, P, ngf, P, P + 6, 32, 1, 7, off=(-3, -3), pad_mode=PAD_REFLECT,
+                 y_pix=4, y_row=Wp * 4, y_img=(P + 12) * Wp * 4)
+    wmap = _wmap(4, -1, ngf * 49, ngf, 1, 49, 28, ngf, 7, tap_mode=2, table=[kh * 7 + 6 for kh in range(7)],
+                 nr_valid=3)
+    assert ops.conv_wgrad_kernel(desc).startswith("patch_wgrad")
+    grad = torch.full((3, ngf, 7, 7), 7.0, device="cuda")
+    ops.conv_wgrad_strided(desc, to_rows(x, dtype), win[:, 6:], wmap, grad, ws_for(ops, desc))
+    torch.cuda.synchronize()
+    assert relmax(grad.cpu(), ref) <= TOL[dtype]

@@ -41,4 +41,4 @@ def test_bad_descriptor_is_rejected_without_a_gpu():
 def test_struct_layout_matches_header():
     from cvae_gan_amd import _lib
     assert C.sizeof(_lib.ConvDesc) == 28 * 4
-    assert C.sizeof(_lib.WMap) == 10 * 4 + 64 * 2
+    assert C.sizeof(_lib.WMap) == 12 * 4 + 64 * 2
