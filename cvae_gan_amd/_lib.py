@@ -77,6 +77,7 @@ def _load():
         "cvg_upsample_pad_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "cvg_reflect_fold": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "cvg_tanh_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "cvg_tail_sum_tanh": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_tanh_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_mse_fwd_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, vp, vp]),
         "cvg_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),

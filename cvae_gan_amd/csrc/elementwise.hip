@@ -588,6 +588,29 @@ __global__ void tanh_fwd(const T* __restrict__ pre, float* __restrict__ dec, int
 #pragma unroll
     for (int c = 0; c < 3; ++c) dec[((size_t)b * 3 + c) * PP + hw] = tanhf(v[c]);
 }
+// Tail finished from per-column partial sums: v[b][y][x'][kw*4 + n] holds the 7 row taps of column
+// x' for kernel column kw, so pre[b][y][x][n] = bias[n] + sum_kw v[b][y][x + kw][kw*4 + n].
+template <typename T>
+__global__ void tail_sum_tanh(const T* __restrict__ v, const float* __restrict__ bias, T* __restrict__ pre,
+                              float* __restrict__ dec, int B, int P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*P*P pixels
+    const int PP = P * P;
+    if (i >= (int64_t)B * PP) return;
+    const int b = (int)(i / PP), hw = (int)(i % PP);
+    const int y = hw / P, x = hw - y * P;
+    const T* row = v + (((size_t)b * P + y) * (P + 6) + x) * 32;
+    float s[4] = {bias[0], bias[1], bias[2], 0.f};
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+        float t[4];
+        load4<T>(row + kw * 32 + kw * 4, t);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[c] += t[c];
+    }
+    store4<T>(pre + (size_t)i * 4, s);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dec[((size_t)b * 3 + c) * PP + hw] = tanhf(s[c]);
+}
 template <typename T>
 __global__ void tanh_bwd(const float* __restrict__ d_dec, const float* __restrict__ dec, T* __restrict__ dpre,
                          T* __restrict__ win, int B, int PP, int P) {
@@ -902,6 +925,14 @@ int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_
 int cvg_tanh_fwd(const void* pre, float* dec, int32_t dtype, int32_t B, int32_t P, cvg_stream stream) {
     CVG_CHECK(pre && dec && B > 0 && P > 0, "tanh_fwd: bad args");
     DISPATCH(dtype, tanh_fwd<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>((const T*)pre, dec, B, P * P));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_tail_sum_tanh(const void* v, const float* bias, void* pre, float* dec, int32_t dtype, int32_t B, int32_t P,
+                      cvg_stream stream) {
+    CVG_CHECK(v && bias && pre && dec && B > 0 && P > 0, "tail_sum_tanh: bad args");
+    DISPATCH(dtype, tail_sum_tanh<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>((const T*)v, bias, (T*)pre,
+                                                                                                dec, B, P));
     CVG_LAUNCH_CHECK();
     return 0;
 }

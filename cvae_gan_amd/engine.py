@@ -471,6 +471,13 @@ class Engine:
         d["tail_wg_map"] = _wmap(4, -1, ngf * 49, ngf, 1, 49, 28, ngf, 7, tap_mode=2,
                                  table=[kh * 7 + 6 for kh in range(7)], nr_valid=3)
         d["tail_wg_dy"] = d["dpre_win"][:, 6:]
+        # forward the same way round: per padded column x', the 7 kernel rows for every kernel column
+        # kw as 32 output channels (kw, n); cvg_tail_sum_tanh adds the 7 columns of each pixel
+        d["tail_v"] = None
+        if ngf % 32 == 0:
+            d["tail_v"] = _Gemm(self, _desc(T, B, P, P, ngf, P, P + 6, 32, 1, 7, off=(-3, -3), pad_mode=PAD_REFLECT),
+                                _wmap(4, 1, ngf * 49, ngf, 7, 49, 28, ngf, 7, nr_valid=3), key + "weight")
+            d["v"] = self._t(B * P * (P + 6), 32)
         # (narrow networks, ngf < 32, keep the 49-tap form on the gather kernel)
         d["tail_wg_windows"] = ops.conv_wgrad_kernel(d["tail_wg_desc"]).startswith("patch_wgrad")
         if d["tail_wg_windows"]:
@@ -665,8 +672,12 @@ class Engine:
             ops.upsample_pad_fwd(x, up["u"], B, up["h"], up["h"], up["cin"])
             self._fwd(up["fwd"], up["u"], up["y"], bias=self.params[up["key"] + "bias"])
             x = up["y"]
-        self._fwd(d["tail"], x, d["pre"], bias=d["tail_bias"])
-        ops.tanh_fwd(d["pre"], d["dec"], B, P)
+        if d["tail_v"] is not None:
+            self._fwd(d["tail_v"], x, d["v"])
+            ops.tail_sum_tanh(d["v"], self.params[d["tail_key"] + "bias"], d["pre"], d["dec"], B, P)
+        else:
+            self._fwd(d["tail"], x, d["pre"], bias=d["tail_bias"])
+            ops.tanh_fwd(d["pre"], d["dec"], B, P)
         return d["dec"]
 
     def dec_backward(self, d_dec, mask=None):

@@ -188,6 +188,10 @@ def tanh_fwd(pre, dec, B, P):
     check(lib.cvg_tanh_fwd(ptr(pre), ptr(dec), dt(pre), B, P, stream()))
 
 
+def tail_sum_tanh(v, bias, pre, dec, B, P):
+    check(lib.cvg_tail_sum_tanh(ptr(v), ptr(bias), ptr(pre), ptr(dec), dt(v), B, P, stream()))
+
+
 def tanh_bwd(d_dec, dec, dpre, B, P, dpre_win=None):
     check(lib.cvg_tanh_bwd(ptr(d_dec), ptr(dec), ptr(dpre), ptr(dpre_win),
                            dt(dpre), B, P, stream()))

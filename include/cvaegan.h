@@ -244,6 +244,14 @@ int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_
  * of a 4-channel image [B][P+12][P+14][4] whose border the caller keeps at zero: the
  * layout the tail's input-gradient convolution reads as 7 row taps of 8-pixel windows. */
 int cvg_tanh_fwd(const void* pre, float* dec, int32_t dtype, int32_t B, int32_t P, cvg_stream s);
+/* Tail conv (nn.Conv2d(64, 3, 7) after ReflectionPad2d(3), networks.py:146-148) finished from
+ * column partials + nn.Tanh: v [B][P][P+6][32] (dtype) holds, for padded column x' and kernel
+ * column kw, the sum over the 7 kernel rows and all input channels at v[..][x'][kw*4 + n] (a
+ * 7-row-tap convolution with 32 "output channels"); pre[b][y][x][n] = bias[n] +
+ * sum_kw v[b][y][x + kw][kw*4 + n] -> pre [B*P*P][4] (dtype) and dec = tanh(pre), NCHW f32.
+ * bias: the canonical 3 floats.                                                             */
+int cvg_tail_sum_tanh(const void* v, const float* bias, void* pre, float* dec, int32_t dtype,
+                      int32_t B, int32_t P, cvg_stream s);
 int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, void* dpre_win, int32_t dtype,
                  int32_t B, int32_t P, cvg_stream s);
 /* Reconstruction loss of models/cvae.py:139: ll = 50 * mean((dec - x)^2) / batch_size,

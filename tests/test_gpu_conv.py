@@ -189,3 +189,32 @@ def test_tail_weight_gradient_through_windows(dtype, B, P, ngf):
     ops.conv_wgrad_strided(desc, to_rows(x, dtype), win[:, 6:], wmap, grad, ws_for(ops, desc))
     torch.cuda.synchronize()
     assert relmax(grad.cpu(), ref) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,P,ngf", [(3, 16, 32), (2, 32, 64)])
+def test_tail_forward_through_column_partials(dtype, B, P, ngf):
+    """7-row-tap convolution with (kernel column, channel) output pairs + cvg_tail_sum_tanh against
+    ReflectionPad2d(3) + Conv2d(ngf, 3, 7) + Tanh (networks.py:146-149)."""
+    ops, _desc, _wmap = _mods()
+    from cvae_gan_amd._lib import PAD_REFLECT
+    g = torch.Generator().manual_seed(B * 100 + P + ngf + 1)
+    x = torch.randn(B, ngf, P, P, generator=g)
+    w = torch.randn(3, ngf, 7, 7, generator=g) / (7 * ngf ** 0.5)
+    bias = torch.randn(3, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref_pre = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w, bias)
+    desc = _desc(dtype, B, P, P, ngf, P, P + 6, 32, 1, 7, off=(-3, -3), pad_mode=PAD_REFLECT)
+    wmap = _wmap(4, 1, ngf * 49, ngf, 7, 49, 28, ngf, 7, nr_valid=3)
+    assert ops.conv_fwd_kernel(desc).startswith("patch_fwd")
+    packed = pack(ops, wmap, w, desc, dtype)
+    v = torch.zeros(B * P * (P + 6), 32, dtype=dtype, device="cuda")
+    ops.conv_fwd(desc, to_rows(x, dtype), packed, v, ws=ws_for(ops, desc))
+    pre = torch.zeros(B * P * P, 4, dtype=dtype, device="cuda")
+    dec = torch.zeros(B, 3, P, P, device="cuda")
+    ops.tail_sum_tanh(v, bias.cuda(), pre, dec, B, P)
+    torch.cuda.synchronize()
+    got_pre = from_rows(pre, B, P, P, 4)[:, :3]
+    assert relmax(got_pre, ref_pre) <= TOL[dtype]
+    assert float((dec.cpu() - torch.tanh(ref_pre)).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
