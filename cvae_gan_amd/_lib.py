@@ -76,6 +76,7 @@ def _load():
         "cvg_upsample_pad_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "cvg_upsample_pad_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "cvg_reflect_fold": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+        "cvg_image_u8_to_f32": (C.c_int, [vp, vp, i32, i32, vp]),
         "cvg_tanh_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "cvg_tail_sum_tanh": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_tanh_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),

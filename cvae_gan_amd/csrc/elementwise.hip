@@ -257,6 +257,16 @@ __global__ void pack_image(const float* __restrict__ x, T* __restrict__ xp, int 
     store4<T>(xp + (size_t)i * 4, v);
 }
 
+// ---- loader output: uint8 HWC (channel order as stored) -> f32 NCHW in [-1, 1] ----------------
+__global__ void image_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int PP) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*PP pixels
+    if (i >= (int64_t)B * PP) return;
+    const int b = (int)(i / PP), hw = (int)(i % PP);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        out[((size_t)b * 3 + c) * PP + hw] = ((float)in[(size_t)i * 3 + c] / 255.f - 0.5f) / 0.5f;
+}
+
 // ---- label fold ------------------------------------------------------------------------------
 __global__ void label_bias(const float* __restrict__ w, float* __restrict__ cbias, int cout, int y_dim) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over y_dim*cout, n fastest
@@ -754,6 +764,13 @@ int cvg_pack_image(const float* x, void* xpad, int32_t B, int32_t P, int32_t dty
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)B * (P + 6) * (P + 8);
     DISPATCH(dtype, pack_image<T><<<grid1(n), 256, 0, s>>>(x, (T*)xpad, B, P));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_image_u8_to_f32(const uint8_t* hwc, float* nchw, int32_t B, int32_t P, cvg_stream stream) {
+    CVG_CHECK(hwc && nchw && B > 0 && P > 0, "image_u8_to_f32: bad args");
+    image_u8_to_f32<<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>(hwc, nchw, B, P * P);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from .datasets import make_dataset
+from .datasets import make_dataset, DevicePrefetcher
 from .engine import Engine, ADAM_BETAS, ADAM_EPS
 
 
@@ -63,8 +63,12 @@ class CVAE(object):
         dtype = getattr(args, "dtype", "bf16")
         self.dtype = torch.float32 if dtype in ("f32", torch.float32) else torch.bfloat16
 
+        # loader items are uint8 images + class indices; normalisation and layout happen on the GPU
+        # behind a pinned, double-buffered copy (set args.device_preprocess = False for the
+        # reference's host-side float pipeline)
+        self.device_preprocess = getattr(args, "device_preprocess", True)
         self.train_data, self.synthetic = make_dataset(args.data_dir, args.dataset, args.pix_dim, args.y_dim,
-                                                       max_size=args.data_size)
+                                                       max_size=args.data_size, raw=self.device_preprocess)
         if self.synthetic:
             print("data directory %r has no %r listing: using the synthetic stand-in"
                   % (args.data_dir, args.dataset))
@@ -117,6 +121,12 @@ class CVAE(object):
         cls = torch.max(labels, 1)[1].to(torch.int32).to(self.device, non_blocking=True)
         return x, cls
 
+    def batches(self):
+        """(x f32 NCHW in [-1, 1], class indices int32), both on the device."""
+        if self.device_preprocess:
+            return DevicePrefetcher(self.trainset_loader, self.batch_size, self.pix_dim, self.device)
+        return (self._to_device(imgs, labels) for imgs, labels in self.trainset_loader)
+
     def train(self):
         hist = self.train_hist = {"VAE_loss": [], "KL_loss": [], "LL_loss": [], "per_epoch_time": [], "total_time": []}
         eng = self.engine
@@ -128,8 +138,7 @@ class CVAE(object):
         for epoch in range(self.epoch):
             epoch_start = time.time()
             it = -1
-            for it, (imgs, labels) in enumerate(self.trainset_loader):
-                x, cls = self._to_device(imgs, labels)
+            for it, (x, cls) in enumerate(self.batches()):
                 eps.normal_()
                 eng.random_mask()
                 eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
@@ -173,8 +182,12 @@ class CVAE(object):
         return out.detach().float().cpu().numpy().transpose(0, 2, 3, 1)
 
     def reconstruct(self, imgs, labels, eps=None):
-        """Eval-mode encoder + decoder (cvae.py:209-213).  imgs [B,3,P,P], labels one-hot [B,y]."""
-        x, cls = self._to_device(imgs, labels)
+        """Eval-mode encoder + decoder (cvae.py:209-213).  imgs [B,3,P,P] in [-1, 1]; labels one-hot
+        [B,y] or class indices [B]."""
+        if labels.dim() == 2:
+            x, cls = self._to_device(imgs, labels)
+        else:
+            x, cls = imgs.to(self.device).float().contiguous(), labels.to(self.device).to(torch.int32)
         eng = self.engine
         assert x.shape[0] == eng.B, "batch size is fixed by --batch_size"
         if eps is None:
@@ -189,10 +202,10 @@ class CVAE(object):
     def test(self):
         iter_num = 10
         ins, outs = [], []
-        for it, (imgs, labels) in enumerate(self.trainset_loader):
-            out = self.reconstruct(imgs, labels)
+        for it, (x, cls) in enumerate(self.batches()):
+            out = self.reconstruct(x, cls)
             outs.append(out.detach().float().cpu().numpy().transpose(0, 2, 3, 1))
-            ins.append(imgs.numpy().transpose(0, 2, 3, 1))
+            ins.append(x.detach().float().cpu().numpy().transpose(0, 2, 3, 1))
             if it + 1 >= iter_num:
                 break
         if not ins:

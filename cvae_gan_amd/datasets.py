@@ -22,9 +22,9 @@ def label_of(name):
 
 
 class BodyMapDataset(Dataset):
-    def __init__(self, data_root, dataset, dim=512, max_size=-1, device=None, transform=None, cls_num=12):
+    def __init__(self, data_root, dataset, dim=512, max_size=-1, device=None, transform=None, cls_num=12, raw=False):
         from PIL import Image  # noqa: F401  (fail here, not in a worker)
-        self.dim, self.cls_num = dim, cls_num
+        self.dim, self.cls_num, self.raw = dim, cls_num, raw
         self.im_root = os.path.join(data_root, dataset)
         names = np.loadtxt(os.path.join(self.im_root, "input_%s.txt" % dataset), dtype=str, ndmin=1)
         self.names = names[:max_size]                    # the reference's slice: -1 drops the last entry
@@ -36,6 +36,9 @@ class BodyMapDataset(Dataset):
     def __getitem__(self, i):
         from PIL import Image
         im = Image.open(self.im_names[i]).convert("RGB").resize((self.dim, self.dim), Image.BILINEAR)
+        if self.raw:                                                      # uint8 HWC BGR + class index: normalised on the device
+            a = np.ascontiguousarray(np.asarray(im, dtype=np.uint8)[:, :, ::-1])
+            return torch.from_numpy(a), label_of(str(self.names[i]))
         a = np.asarray(im, dtype=np.float32)[:, :, ::-1]                  # RGB -> BGR, as cv2.imread
         img = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))) / 255.0
         img = (img - 0.5) / 0.5
@@ -47,8 +50,8 @@ class BodyMapDataset(Dataset):
 class SyntheticBodyMaps(Dataset):
     """Deterministic stand-in: image i has class i % cls_num; a class moves a Gaussian blob."""
 
-    def __init__(self, n, dim, cls_num, seed=0):
-        self.n, self.dim, self.cls_num, self.seed = n, dim, cls_num, seed
+    def __init__(self, n, dim, cls_num, seed=0, raw=False):
+        self.n, self.dim, self.cls_num, self.seed, self.raw = n, dim, cls_num, seed, raw
         g = torch.linspace(-1, 1, dim)
         self.yy, self.xx = torch.meshgrid(g, g, indexing="ij")
 
@@ -63,15 +66,81 @@ class SyntheticBodyMaps(Dataset):
         blob = torch.exp(-((self.xx - cx) ** 2 + (self.yy - cy) ** 2) / 0.08)
         img = torch.stack([blob, blob.flip(0), blob.flip(1)]) * 1.6 - 0.9
         img = (img + 0.05 * torch.randn(3, self.dim, self.dim, generator=gen)).clamp(-1, 1)
+        if self.raw:
+            u8 = ((img * 0.5 + 0.5) * 255.0).round().clamp(0, 255).to(torch.uint8)
+            return u8.permute(1, 2, 0).contiguous(), c
         y = torch.zeros(self.cls_num)
         y[c] = 1
         return img, y
 
 
-def make_dataset(data_dir, dataset, pix_dim, cls_num, max_size=-1, synthetic_size=2048):
-    """The reference's dataset when its files exist, the synthetic stand-in otherwise."""
+def make_dataset(data_dir, dataset, pix_dim, cls_num, max_size=-1, synthetic_size=2048, raw=False):
+    """The reference's dataset when its files exist, the synthetic stand-in otherwise.
+    raw=True: items are (uint8 HWC image, class index) for DevicePrefetcher."""
     listing = os.path.join(data_dir, dataset, "input_%s.txt" % dataset)
     if os.path.exists(listing):
-        return BodyMapDataset(data_dir, dataset, dim=pix_dim, max_size=max_size, cls_num=cls_num), False
+        return BodyMapDataset(data_dir, dataset, dim=pix_dim, max_size=max_size, cls_num=cls_num, raw=raw), False
     n = synthetic_size if max_size is None or max_size < 0 else max_size
-    return SyntheticBodyMaps(n, pix_dim, cls_num), True
+    return SyntheticBodyMaps(n, pix_dim, cls_num, raw=raw), True
+
+
+class DevicePrefetcher:
+    """Replaces the reference's DataLoaderX / BackgroundGenerator (models/cvae.py:18-21): batches
+    of (uint8 HWC images, class indices) from a DataLoader go through pinned host buffers to the
+    GPU on a copy stream, one batch ahead of the consumer, and are normalised there
+    (cvg_image_u8_to_f32).  Yields (x f32 NCHW in [-1, 1], labels int32), both on the device and
+    valid until the next-but-one batch is requested (two buffer sets)."""
+
+    def __init__(self, loader, batch_size, pix_dim, device):
+        from . import ops
+        self.loader, self.ops, self.B, self.P = loader, ops, batch_size, pix_dim
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.sets = []
+        for _ in range(2):
+            self.sets.append(dict(
+                h_img=torch.empty(batch_size, pix_dim, pix_dim, 3, dtype=torch.uint8).pin_memory(),
+                h_lab=torch.empty(batch_size, dtype=torch.int32).pin_memory(),
+                d_img=torch.empty(batch_size, pix_dim, pix_dim, 3, dtype=torch.uint8, device=self.device),
+                d_lab=torch.empty(batch_size, dtype=torch.int32, device=self.device),
+                x=torch.empty(batch_size, 3, pix_dim, pix_dim, dtype=torch.float32, device=self.device),
+                ready=torch.cuda.Event(), consumed=torch.cuda.Event()))
+        for s in self.sets:
+            s["consumed"].record()
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, s, imgs, labels):
+        s["consumed"].synchronize()                       # the consumer's kernels on this set have run
+        s["h_img"].copy_(imgs)
+        s["h_lab"].copy_(torch.as_tensor(labels).to(torch.int32))
+        with torch.cuda.stream(self.copy_stream):
+            s["d_img"].copy_(s["h_img"], non_blocking=True)
+            s["d_lab"].copy_(s["h_lab"], non_blocking=True)
+            self.ops.image_u8_to_f32(s["d_img"], s["x"], self.B, self.P)
+            s["ready"].record()
+
+    def __iter__(self):
+        it = iter(self.loader)
+        k = 0
+        try:
+            imgs, labels = next(it)
+        except StopIteration:
+            return
+        self._stage(self.sets[0], imgs, labels)
+        while True:
+            cur = self.sets[k % 2]
+            nxt = None
+            try:
+                imgs, labels = next(it)
+                nxt = self.sets[(k + 1) % 2]
+                self._stage(nxt, imgs, labels)
+            except StopIteration:
+                pass
+            torch.cuda.current_stream().wait_event(cur["ready"])
+            yield cur["x"], cur["d_lab"]
+            cur["consumed"].record()                      # on the consumer's stream, after its launches
+            if nxt is None:
+                return
+            k += 1

@@ -188,6 +188,11 @@ def tanh_fwd(pre, dec, B, P):
     check(lib.cvg_tanh_fwd(ptr(pre), ptr(dec), dt(pre), B, P, stream()))
 
 
+def image_u8_to_f32(hwc_u8, nchw_f32, B, P):
+    assert hwc_u8.dtype == torch.uint8 and nchw_f32.dtype == torch.float32
+    check(lib.cvg_image_u8_to_f32(ptr(hwc_u8), ptr(nchw_f32), B, P, stream()))
+
+
 def tail_sum_tanh(v, bias, pre, dec, B, P):
     check(lib.cvg_tail_sum_tanh(ptr(v), ptr(bias), ptr(pre), ptr(dec), dt(v), B, P, stream()))
 

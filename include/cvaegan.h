@@ -161,6 +161,11 @@ int cvg_label_bias_bwd(const void* dy, int32_t dtype, const int32_t* labels, int
 
 /* ---- HBM-bound kernels ---------------------------------------------------------- */
 
+/* Loader output on the device: uint8 images [B][P][P][3] (channel order as stored, BGR for
+ * cv2.imread) -> f32 NCHW [B,3,P,P] = (v/255 - .5)/.5, i.e. ToTensor + Normalize(.5, .5) of
+ * datasets.py:14-18 after the H2D copy (a quarter of the bytes of the f32 batch).          */
+int cvg_image_u8_to_f32(const uint8_t* hwc, float* nchw, int32_t B, int32_t P, cvg_stream s);
+
 /* images NCHW f32 [B,3,P,P] -> reflection-padded NHWC4 [B][P+6][P+8][4] (dtype),
  * channel 3 and the two extra columns are zero (nn.ReflectionPad2d(3), networks.py:172). */
 int cvg_pack_image(const float* x, void* xpad, int32_t B, int32_t P, int32_t dtype, cvg_stream s);

@@ -84,3 +84,19 @@ def test_trainer_runs_saves_and_reloads(tmp_path):
     assert os.path.exists(path)
     grid = m2.sample_grid()
     assert grid.shape == (10 * 4, 32, 32, 3) and np.isfinite(grid).all() and np.abs(grid).max() <= 1.0
+
+
+def test_device_prefetcher_matches_host_pipeline(tmp_path):
+    """uint8 batches normalised on the GPU (cvg_image_u8_to_f32 behind pinned double buffers) equal
+    ToTensor + Normalize(.5, .5) of the same bytes (reference datasets.py:14-18), batch after batch."""
+    from torch.utils.data import DataLoader
+    from cvae_gan_amd.datasets import SyntheticBodyMaps, DevicePrefetcher
+    ds = SyntheticBodyMaps(40, 16, 5, raw=True)
+    loader = DataLoader(ds, batch_size=8, shuffle=False, drop_last=True)
+    got = [(x.clone(), l.clone()) for x, l in DevicePrefetcher(loader, 8, 16, "cuda")]
+    assert len(got) == 5
+    for k, (x, l) in enumerate(got):
+        u8 = torch.stack([ds[8 * k + i][0] for i in range(8)])                 # [8,16,16,3]
+        ref = ((u8.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
+        assert torch.allclose(x.cpu(), ref, atol=1e-6)
+        assert l.cpu().tolist() == [(8 * k + i) % 5 for i in range(8)]
