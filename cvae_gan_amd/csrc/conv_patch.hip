@@ -167,6 +167,39 @@ patch_fwd(const PatchFwdArgs a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+    // A residual term (res * LeakyReLU'(gate), the skip branch of a res block's input gradient)
+    // starts the accumulators: its scattered 8-byte reads are in flight while the first patch and
+    // the weight ring fill, instead of sitting in the epilogue.
+    if (a.res) {
+        const T* __restrict__ resp = (const T*)a.res;
+        const T* __restrict__ gatep = (const T*)a.gate;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ql = wm * WTM + mi * 32 + lane_pixel(l31, a.lane_perm);
+            int tb, ty, tx;
+            tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            if (!(ql < t.npx && b < a.B && oy < a.OH && ox < a.OW)) continue;
+            const int yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + wn * WTN + ni * 32 + 8 * g4 + 4 * h;
+                    if (n >= a.N) continue;
+                    float r[4];
+                    load4<T>(resp + yoff + n, r);
+                    if (gatep) {
+                        float gt[4];
+                        load4<T>(gatep + yoff + n, gt);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g4 + j] = r[j];
+                }
+        }
+    }
 
     frag wr[TU][NI][2];
     auto load_w = [&](int step, frag (&w)[NI][2]) {
@@ -240,22 +273,16 @@ patch_fwd(const PatchFwdArgs a) {
     // its last read) and leaves as whole pixel rows, 16 bytes per lane, consecutive lanes on
     // consecutive addresses.
     constexpr int OP = BN * ES + 16;             // staged row pitch
-    const T* __restrict__ resp = (const T*)a.res;
-    const T* __restrict__ gatep = (const T*)a.gate;
-    const bool per_pixel = a.cbias != nullptr || resp != nullptr;    // epilogue terms that need the pixel's address
+    const bool per_pixel = a.cbias != nullptr;   // the class bias needs the pixel's image
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int ql = wm * WTM + mi * 32 + lpx;
-        bool live = true;
-        int yoff = 0;
         const float* cb = nullptr;
         if (per_pixel) {
             int tb, ty, tx;
             tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
-            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-            live = ql < t.npx && b < a.B && oy < a.OH && ox < a.OW;
-            yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
-            if (a.cbias && live) cb = a.cbias + (size_t)a.labels[b] * a.N;
+            const int b = b0 + tb;
+            if (ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -273,18 +300,6 @@ patch_fwd(const PatchFwdArgs a) {
                     if (cb) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
-                    }
-                    if (resp && live) {
-                        float r[4];
-                        load4<T>(resp + yoff + n, r);
-                        if (gatep) {
-                            float gt[4];
-                            load4<T>(gatep + yoff + n, gt);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += r[j];
                     }
                 }
                 store4<T>((T*)(smem + ql * OP) + nl, v);
