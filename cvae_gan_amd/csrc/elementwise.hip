@@ -12,13 +12,15 @@ __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLO
 
 // ---- column reductions over rows[M][ld] ----------------------------------------------
 // Thread layout: chunk = tid % CC handles 8 channels, rl = tid / CC strides the rows.
-enum { RED_STATS = 0, RED_BNBWD = 1, RED_SUM = 2 };
+enum { RED_STATS = 0, RED_BNBWD = 1, RED_SUM = 2, RED_BNBWD_X = 3 };   // _X: gate recomputed from x, y not read
 
 struct RedArgs {
     const void* x;       // STATS/SUM: input rows; BNBWD: conv output x
     const void* dy;      // BNBWD
-    const void* y;       // BNBWD: activation output (sign source)
+    const void* y;       // BNBWD: activation output (sign source), or null: the sign of gamma*xhat+beta
     const float* stats;  // BNBWD: mean[C], invstd[C]
+    const float* gamma;  // BNBWD without y
+    const float* beta;
     float* ws;           // partials [2][nblk][C]
     int M, C, ld, nblk;
     int Cb;              // columns handled per blockIdx.y (== C unless C > 1024)
@@ -34,10 +36,16 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     float s0[8], s1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
-    float mean[8], istd[8];
-    if (MODE == RED_BNBWD) {
+    float mean[8], istd[8], sc[8], sh[8];
+    constexpr bool from_x = MODE == RED_BNBWD_X;
+    if (MODE == RED_BNBWD || from_x) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { mean[j] = a.stats[c_off + chunk * 8 + j]; istd[j] = a.stats[a.C + c_off + chunk * 8 + j]; }
+        for (int j = 0; j < 8; ++j) {
+            const int c = c_off + chunk * 8 + j;
+            mean[j] = a.stats[c]; istd[j] = a.stats[a.C + c];
+            sc[j] = sh[j] = 0.f;
+            if (from_x) { sc[j] = a.gamma[c] * istd[j]; sh[j] = a.beta[c] - mean[j] * sc[j]; }   // as bn_act_fwd
+        }
     }
     if (rl < RL) {
         for (int64_t m = (int64_t)blockIdx.x * RL + rl; m < a.M; m += (int64_t)gridDim.x * RL) {
@@ -53,7 +61,12 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
             } else {
                 float d[8], o[8];
                 load8<T>((const T*)a.dy + off, d);
-                load8<T>((const T*)a.y + off, o);
+                if (from_x) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = v[j] * sc[j] + sh[j];
+                } else {
+                    load8<T>((const T*)a.y + off, o);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
@@ -177,15 +190,16 @@ __global__ void __launch_bounds__(256) bn_act_fwd(const T* __restrict__ x, const
     }
 }
 
-template <typename T>
+template <typename T, bool from_x>   // from_x: gate = sign of gamma*xhat + beta, recomputed as bn_act_fwd does
 __global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, const T* __restrict__ y,
                                                      const T* __restrict__ x, T* __restrict__ dx, int M, int C,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
     const int CC = C / 8, RL = blockDim.x / CC;
     const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
     if (rl >= RL) return;
-    float mean[8], istd[8], k0[8], k1[8], k2[8];
+    float mean[8], istd[8], k0[8], k1[8], k2[8], sh[8];
     const float invM = 1.f / (float)M;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -195,13 +209,19 @@ __global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, c
         k0[j] = gamma[c] * istd[j];
         k1[j] = dbeta[c] * invM;
         k2[j] = dgamma[c] * invM;
+        sh[j] = from_x ? beta[c] - mean[j] * k0[j] : 0.f;
     }
     for (int64_t m = (int64_t)blockIdx.x * RL + rl; m < M; m += (int64_t)gridDim.x * RL) {
         const size_t off = (size_t)m * C + chunk * 8;
         float d[8], o[8], v[8];
         load8<T>(dy + off, d);
-        load8<T>(y + off, o);
         load8<T>(x + off, v);
+        if (from_x) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[j] * k0[j] + sh[j];
+        } else {
+            load8<T>(y + off, o);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
@@ -782,7 +802,7 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     if (check_rows("bn_stats", M, C)) return -1;
     CVG_CHECK(x && stats && ws, "bn_stats: null");
     hipStream_t s = (hipStream_t)stream;
-    RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
     DISPATCH(dtype, colreduce<T, RED_STATS><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
@@ -811,21 +831,28 @@ int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32
 }
 
 int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32_t dtype, int32_t M, int32_t C,
-                   const float* stats, const float* gamma, float* dgamma, float* dbeta, float* ws,
+                   const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* ws,
                    cvg_stream stream) {
     if (check_rows("bn_act_bwd", M, C)) return -1;
-    CVG_CHECK(dy && y && x && dx && stats && gamma && dgamma && dbeta && ws, "bn_act_bwd: null");
+    CVG_CHECK(dy && x && dx && stats && gamma && dgamma && dbeta && ws, "bn_act_bwd: null");
+    CVG_CHECK(y || beta, "bn_act_bwd: without y the gate needs beta");
     hipStream_t s = (hipStream_t)stream;
-    RedArgs a = {x, dy, y, stats, ws, M, C, C, red_blocks(M, C), C};
-    DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
+    RedArgs a = {x, dy, y, stats, gamma, beta, ws, M, C, C, red_blocks(M, C), C};
+    if (y) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
+    else DISPATCH(dtype, colreduce<T, RED_BNBWD_X><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
     CVG_LAUNCH_CHECK();
     const int RL = 256 / (C / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
     if (nb > 4096) nb = 4096;
-    DISPATCH(dtype, bn_act_bwd_dx<T><<<nb, red_threads(C), 0, s>>>((const T*)dy, (const T*)y, (const T*)x, (T*)dx, M, C,
-                                                                   stats, gamma, dgamma, dbeta));
+    if (y) {
+        DISPATCH(dtype, bn_act_bwd_dx<T, false><<<nb, red_threads(C), 0, s>>>((const T*)dy, (const T*)y, (const T*)x, (T*)dx,
+                                                                              M, C, stats, gamma, beta, dgamma, dbeta));
+    } else {
+        DISPATCH(dtype, bn_act_bwd_dx<T, true><<<nb, red_threads(C), 0, s>>>((const T*)dy, nullptr, (const T*)x, (T*)dx,
+                                                                             M, C, stats, gamma, beta, dgamma, dbeta));
+    }
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -836,7 +863,7 @@ int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, f
     CVG_CHECK(x && out && ws && ld >= C && ld % 8 == 0 && md > 0, "colsum: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
-    RedArgs a = {x, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
     DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, C / Cb), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);

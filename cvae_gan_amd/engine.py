@@ -535,8 +535,10 @@ class Engine:
         ops.bn_act_fwd(x, res, y, M, C, stats, self.params[prefix + ".weight"], self.params[prefix + ".bias"])
 
     def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix):
+        """y=None for a BatchNorm without a residual input: the gate is recomputed from x."""
         ops.bn_act_bwd(dy, y, x, dx, M, C, stats, self.params[prefix + ".weight"],
-                       self.grads[prefix + ".weight"], self.grads[prefix + ".bias"], self.red_ws)
+                       self.grads[prefix + ".weight"], self.grads[prefix + ".bias"], self.red_ws,
+                       beta=self.params[prefix + ".bias"])
 
     def _ready(self, stage):
         if self.grad_ready is not None:
@@ -606,7 +608,7 @@ class Engine:
             self._wgrad(e["fc3"], e["f1"], dh, e["nz"])
             ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws_side)
         self._fwd(e["fc3_dg"], dh, e["d_f1"])
-        self._bn_bwd(e["d_f1"], e["f1"], e["f0"], e["d_f0"], B, e["fcd"], e["stf"], EP + "fc.1")
+        self._bn_bwd(e["d_f1"], None, e["f0"], e["d_f0"], B, e["fcd"], e["stf"], EP + "fc.1")
         with self._branch():
             self._wgrad(e["fc0"], last["out"], e["d_f0"], e["fcd"])
             ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws_side)
@@ -622,14 +624,14 @@ class Engine:
             with self._branch():
                 self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
             self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"])
-            self._bn_bwd(blk["d_b1"], blk["b1"], blk["c1"], blk["d_c1"], M, C, blk["st1"], p + "res.res.1")
+            self._bn_bwd(blk["d_b1"], None, blk["c1"], blk["d_c1"], M, C, blk["st1"], p + "res.res.1")
             with self._branch():
                 self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
             d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
             # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
             self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
             self._ready("enc.blk%d" % i)
-        self._bn_bwd(e["d_a0"], e["a0"], e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
+        self._bn_bwd(e["d_a0"], None, e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
         with self._branch():
             self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
             ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],

@@ -137,8 +137,9 @@ def bn_act_fwd(x, res, y, M, C_, stats, gamma, beta):
     check(lib.cvg_bn_act_fwd(ptr(x), ptr(res), ptr(y), dt(x), M, C_, ptr(stats), ptr(gamma), ptr(beta), stream()))
 
 
-def bn_act_bwd(dy, y, x, dx, M, C_, stats, gamma, dgamma, dbeta, ws):
-    check(lib.cvg_bn_act_bwd(ptr(dy), ptr(y), ptr(x), ptr(dx), dt(x), M, C_, ptr(stats), ptr(gamma),
+def bn_act_bwd(dy, y, x, dx, M, C_, stats, gamma, dgamma, dbeta, ws, beta=None):
+    """y=None (with beta): the activation's sign is recomputed from x instead of read from y."""
+    check(lib.cvg_bn_act_bwd(ptr(dy), ptr(y), ptr(x), ptr(dx), dt(x), M, C_, ptr(stats), ptr(gamma), ptr(beta),
                              ptr(dgamma), ptr(dbeta), ptr(ws), stream()))
 
 

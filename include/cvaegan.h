@@ -188,9 +188,12 @@ int cvg_bn_eval_stats(const float* running_mean, const float* running_var, int32
 /* Backward of the same: g = dy * (y > 0 ? 1 : 0.2);
  * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
  * The residual branch's gradient is g itself; consumers recompute it from (dy, y)
- * through cvg_conv_fwd's res/gate arguments.  ws as for cvg_bn_stats.             */
+ * through cvg_conv_fwd's res/gate arguments.  ws as for cvg_bn_stats.
+ * y may be NULL for a BatchNorm without a residual input: the sign of the activation is then
+ * recomputed from x (gamma * xhat + beta, the expression cvg_bn_act_fwd evaluates), which
+ * saves one of the three tensor reads of both passes; beta is only read in that case.   */
 int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32_t dtype,
-                   int32_t M, int32_t C, const float* stats, const float* gamma,
+                   int32_t M, int32_t C, const float* stats, const float* gamma, const float* beta,
                    float* dgamma, float* dbeta, float* ws, cvg_stream s);
 
 /* Column sums of rows[M][ld] over the first C columns -> out[C] (bias gradients).

@@ -218,3 +218,53 @@ def test_tail_forward_through_column_partials(dtype, B, P, ngf):
     got_pre = from_rows(pre, B, P, P, 4)[:, :3]
     assert relmax(got_pre, ref_pre) <= TOL[dtype]
     assert float((dec.cpu() - torch.tanh(ref_pre)).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,with_res", [(3000, 64, False), (3000, 64, True), (517, 128, False), (96, 256, True)])
+def test_batchnorm_leakyrelu_forward_backward(dtype, M, C, with_res):
+    """cvg_bn_stats + cvg_bn_act_fwd + cvg_bn_act_bwd against torch autograd on the CPU.
+    Without a residual input the backward is run twice: with the gate read from y and with the
+    gate recomputed from x (y = NULL); the two must agree bit for bit."""
+    ops, _, _ = _mods()
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    res = torch.randn(M, C, generator=g) if with_res else None
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(M, C, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        res = res.bfloat16().float() if with_res else None
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    pre = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    yr = F.leaky_relu(pre + res if with_res else pre, 0.2)
+    yr.backward(dy)
+
+    dev = lambda t: t.to(dtype).cuda().contiguous()
+    f32 = lambda t: t.float().cuda().contiguous()
+    xd, dyd = dev(x), dev(dy)
+    yd, dxd = torch.empty_like(xd), torch.empty_like(xd)
+    stats = torch.zeros(2 * C, device="cuda")
+    rm, rv, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(2 * 1024 * 1024, device="cuda")
+    gd, bd = f32(gamma), f32(beta)
+    ops.bn_stats(xd, M, C, stats, rm, rv, nbt, ws)
+    ops.bn_act_fwd(xd, dev(res) if with_res else None, yd, M, C, stats, gd, bd)
+    tol = TOL[dtype]
+    assert relmax(yd.float().cpu(), yr.detach()) <= tol
+    # gradients are compared with the gate torch used, so feed the backward torch's y
+    yd = dev(yr.detach())
+    outs = []
+    for y_arg in ([yd] if with_res else [yd, None]):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dxd.zero_()
+        ops.bn_act_bwd(dyd, y_arg, xd, dxd, M, C, stats, gd, dg, db, ws, beta=bd)
+        torch.cuda.synchronize()
+        outs.append((dxd.clone(), dg.clone(), db.clone()))
+        assert relmax(dg.cpu(), gr.grad) <= max(tol, 1e-4)
+        assert relmax(db.cpu(), br.grad) <= max(tol, 1e-4)
+        assert relmax(dxd.float().cpu(), xr.grad) <= max(tol, 1e-4)
+    if not with_res and dtype == torch.float32:
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
