@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcvaegan_hip.so")
+LIB_PATH = os.environ.get("CVG_LIB") or os.path.join(_HERE, "lib", "libcvaegan_hip.so")   # CVG_LIB: A/B builds
 
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1

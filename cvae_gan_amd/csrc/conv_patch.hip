@@ -35,6 +35,9 @@ struct PatchFwdArgs {
     int nchunks, patch_px, patch_bytes;
     int lane_perm;                          // tile rows are 16 pixels wide: use lane_pixel()
     int row_fast;                           // tile rows hold a multiple of the epilogue's pixels per thread
+#ifdef EXP_TIMING
+    long long* dbg;
+#endif
     TileGeom t;
 };
 
@@ -103,6 +106,31 @@ patch_fwd(const PatchFwdArgs a) {
     const int tile_y = fdiv(blockIdx.x, t.div_tx), tile_x = blockIdx.x - tile_y * t.tiles_x;
     const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = blockIdx.z * t.TB, n0 = blockIdx.y * BN;
     const T* __restrict__ xp = (const T*)a.x;
+#ifdef EXP_TIMING
+    long long tt[5];
+    const long long wall0 = wall_clock64();
+    tt[0] = __builtin_readcyclecounter();
+#endif
+
+    // ---- weight fragment streams (one per 32-row block of this wave).  The ring of the first TU
+    // steps is requested before anything else: its 2*TU*NI KiB per wave take the texture path a few
+    // thousand cycles, which the address arithmetic below fills.
+    const int nsteps = a.nchunks * a.T;          // (chunk, tap) steps; two k16 fragments each
+    const T* wptr[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        wptr[ni] = (const T*)a.wf + ((size_t)((n0 + wn * WTN) / 32 + ni) * nsteps * 2) * FRAG + lane * 8;
+    frag wr[TU][NI][2];
+    auto load_w = [&](int step, frag (&w)[NI][2]) {
+        step = min(step, nsteps - 1);            // the tail re-reads the last step instead of branching
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            w[ni][0] = *(const frag*)(wptr[ni] + (size_t)(step * 2) * FRAG);
+            w[ni][1] = *(const frag*)(wptr[ni] + (size_t)(step * 2 + 1) * FRAG);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);
 
     // ---- patch pieces of this thread: global element offset at chunk 0; padding pieces read
     // element 0 and are zeroed by `pmask` afterwards (no branch around the loads)
@@ -131,13 +159,23 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) pv[i] = *(const u32x4*)(xp + (size_t)gofs[i] + chunk * CK);
     };
+    load_patch(0);                               // in flight during the rest of the set-up
+    // Branch-free on purpose: a store inside a conditional block puts the wait for its load inside
+    // that block too, and the loop then has to drain every outstanding load (the whole weight ring)
+    // before the next patch load may reuse the registers.  Pieces beyond the patch go to the 16
+    // padding bytes of patch pixel 0, which nothing reads.
+    int sofs[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + NT * i;
+        sofs[i] = idx < nitems ? (idx / CPP) * PITCH + (idx % CPP) * 16 : CK * ES;
+    }
     auto store_patch = [&](char* buf) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + NT * i;
             u32x4 v = pv[i];
             if (!((pmask >> i) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
-            if (idx < nitems) *(u32x4*)(buf + (idx / CPP) * PITCH + (idx % CPP) * 16) = v;
+            *(u32x4*)(buf + sofs[i]) = v;
         }
     };
 
@@ -152,13 +190,6 @@ patch_fwd(const PatchFwdArgs a) {
         tile_px(t, q, tb, ty, tx);
         abase[mi] = ((tb * t.PH + ty) * t.PW + tx) * PITCH + 8 * h * ES;
     }
-
-    // ---- weight fragment streams (one per 32-row block of this wave)
-    const int nsteps = a.nchunks * a.T;          // (chunk, tap) steps; two k16 fragments each
-    const T* wptr[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-        wptr[ni] = (const T*)a.wf + ((size_t)((n0 + wn * WTN) / 32 + ni) * nsteps * 2) * FRAG + lane * 8;
 
     f32x16 acc[NI][MI];
 #pragma unroll
@@ -201,28 +232,32 @@ patch_fwd(const PatchFwdArgs a) {
         }
     }
 
-    frag wr[TU][NI][2];
-    auto load_w = [&](int step, frag (&w)[NI][2]) {
-        step = min(step, nsteps - 1);            // the tail re-reads the last step instead of branching
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            w[ni][0] = *(const frag*)(wptr[ni] + (size_t)(step * 2) * FRAG);
-            w[ni][1] = *(const frag*)(wptr[ni] + (size_t)(step * 2 + 1) * FRAG);
-        }
-    };
-
-    load_patch(0);
-#pragma unroll
-    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);
+#ifdef EXP_TIMING
+    long long tp[3];
+    tp[0] = __builtin_readcyclecounter();
+#endif
+#ifdef EXP_TIMING
+    tp[1] = __builtin_readcyclecounter();
+#endif
     store_patch(smem);
+#ifdef EXP_TIMING
+    tp[2] = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef EXP_TIMING
+    tt[1] = __builtin_readcyclecounter();
+#endif
     load_patch(min(1, a.nchunks - 1));
 
-    const int ngrp = a.T / TU;
+    // groups of TU taps per chunk: a compile-time count, so the compiler knows how many weight loads
+    // are younger than the patch loads when store_patch waits for them (with a run-time count it has
+    // to assume none and drains the whole ring at every chunk boundary)
+    constexpr int NGRP = (KWT == 1 ? 7 : KWT * KWT) / TU;
     int step = 0;
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const char* buf = smem + (chunk & 1) * a.patch_bytes;
-        for (int grp = 0; grp < ngrp; ++grp) {
+#pragma unroll 1
+        for (int grp = 0; grp < NGRP; ++grp) {
             // PIPE (one wave per SIMD, registers to spare): the LDS reads of step j+1 are issued
             // before the MFMAs of step j, so the matrix pipe never waits for LDS inside a group.
             constexpr bool PIPE = NI >= 2;
@@ -272,6 +307,9 @@ patch_fwd(const PatchFwdArgs a) {
     // through LDS instead (the patch buffers are free: every wave passed the barrier that follows
     // its last read) and leaves as whole pixel rows, 16 bytes per lane, consecutive lanes on
     // consecutive addresses.
+#ifdef EXP_TIMING
+    tt[2] = __builtin_readcyclecounter();
+#endif
     constexpr int OP = BN * ES + 16;             // staged row pitch
     const bool per_pixel = a.cbias != nullptr;   // the class bias needs the pixel's image
 #pragma unroll
@@ -307,6 +345,21 @@ patch_fwd(const PatchFwdArgs a) {
         }
     }
     __syncthreads();
+#ifdef EXP_TIMING
+    tt[3] = __builtin_readcyclecounter();
+    auto finish = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        tt[4] = __builtin_readcyclecounter();
+        if (tid == 0) {
+            const size_t lin = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+            if (lin < 65536) {
+                for (int k = 0; k < 5; ++k) a.dbg[lin * 5 + k] = tt[k];
+                for (int k = 0; k < 2; ++k) a.dbg[65536 * 5 + lin * 3 + k] = tp[k] - tt[0];
+                a.dbg[65536 * 5 + lin * 3 + 2] = wall_clock64() - wall0;
+            }
+        }
+    };
+#endif
     // Second half: thread -> (16-byte piece pc of the row, PT consecutive tile pixels).  When the tile
     // rows hold a multiple of PT pixels (a.row_fast) the PT pixels share one output row: one address
     // computation, then a fixed step per pixel.
@@ -337,6 +390,9 @@ patch_fwd(const PatchFwdArgs a) {
             if (ox + i < a.OW) put(q0 + i, yoff);
             yoff += step;
         }
+#ifdef EXP_TIMING
+        finish();
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
@@ -348,6 +404,9 @@ patch_fwd(const PatchFwdArgs a) {
             if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
             put(q, b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch);
         }
+#ifdef EXP_TIMING
+        finish();
+#endif
     }
 }
 
@@ -934,6 +993,40 @@ int launch_patch_wgrad(const PatchWgradPlan& p, const PatchWgradArgs& a, hipStre
 
 }  // namespace
 
+#ifdef EXP_TIMING
+#include <vector>
+#include <algorithm>
+static long long* g_dbg = nullptr;
+static long long g_dbg_blocks = 0;
+extern "C" void cvg_debug_timing_dump() {
+    if (!g_dbg) return;
+    (void)hipDeviceSynchronize();
+    const long long n = std::min<long long>(g_dbg_blocks, 65536);
+    std::vector<long long> h(n * 5);
+    (void)hipMemcpy(h.data(), g_dbg, n * 5 * 8, hipMemcpyDeviceToHost);
+    long long tmin = h[0], tmax = h[4];
+    double ph[4] = {0, 0, 0, 0};
+    for (long long i = 0; i < n; ++i) {
+        tmin = std::min(tmin, h[i * 5]); tmax = std::max(tmax, h[i * 5 + 4]);
+        for (int k = 0; k < 4; ++k) ph[k] += (double)(h[i * 5 + k + 1] - h[i * 5 + k]);
+    }
+    printf("timing over %lld workgroups: span %lld ticks; mean prologue %.0f  main loop %.0f  stage %.0f  store %.0f  (ticks)\n",
+           n, tmax - tmin, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+    {
+        std::vector<long long> q(n * 3);
+        (void)hipMemcpy(q.data(), g_dbg + 65536 * 5, n * 3 * 8, hipMemcpyDeviceToHost);
+        double m[3] = {0, 0, 0};
+        for (long long i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) m[k] += (double)q[i * 3 + k];
+        printf("  geometry done at %.0f ticks; workgroup lifetime %.0f wall ticks (100 MHz) = %.2f us -> shader clock %.0f MHz\n", m[0] / n,
+               m[2] / n, m[2] / n / 100.0, (ph[0] + ph[1] + ph[2] + ph[3]) / m[2] * 100.0);
+    }
+    // start-time histogram in 10 bins of the span
+    int hist[10] = {0};
+    for (long long i = 0; i < n; ++i) hist[std::min<long long>(9, (h[i * 5] - tmin) * 10 / std::max<long long>(1, tmax - tmin))]++;
+    printf("start-time histogram:"); for (int k = 0; k < 10; ++k) printf(" %d", hist[k]); printf("\n");
+}
+#endif
+
 void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     p.ok = 0;
     if (!patch_eligible(d)) return;
@@ -987,6 +1080,14 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
         const int pt = p.BM * (p.BN * es / 16) / threads;
         a.row_fast = (p.TW % pt == 0) ? 1 : 0;
     }
+#ifdef EXP_TIMING
+    {
+        static long long* dbg = nullptr;
+        if (!dbg) { if (hipMalloc(&dbg, 65536 * 8 * 8) != hipSuccess) return -1; }
+        a.dbg = dbg;
+        g_dbg = dbg; g_dbg_blocks = (long long)p.tiles_y * p.tiles_x * ceil_div(d->N, p.BN) * p.groups;
+    }
+#endif
     fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
     // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.

@@ -1,10 +1,7 @@
-for e in 0 1; do
-if [ $e = 1 ]; then export CVG_PATCH_PERSIST=1; else unset CVG_PATCH_PERSIST; fi
-echo "PERSIST=$e"
-timeout -k 10 100 python tools/layer_bench.py 256 64 32 64 3 1 fwd 30 || exit 1
-timeout -k 10 100 python tools/layer_bench.py 256 64 64 64 3 1 fwd 30 || exit 1
-timeout -k 10 100 python tools/layer_bench.py 256 64 128 64 3 0 fwd 30 || exit 1
-timeout -k 10 100 python tools/layer_bench.py 256 32 128 128 3 1 fwd 30 || exit 1
-timeout -k 10 100 python tools/layer_bench.py 256 16 256 256 3 1 fwd 30 || exit 1
-timeout -k 10 100 python tools/layer_bench.py 256 66 64 128 3 1 fwd 30 || exit 1
+# Scratch: phase timing of patch_fwd from the instrumented experiment build, then the product build.
+for lib in build_exp/lib_T.so; do
+if [ -n "$lib" ]; then export CVG_LIB=$PWD/$lib; else unset CVG_LIB; fi
+for a in "256 32 128 128 3 1" "256 16 256 256 3 1" "256 64 64 64 3 1" "256 66 64 128 3 1"; do
+timeout -k 10 100 python tools/layer_bench.py $a fwd 20 || exit 1
+done
 done

@@ -59,6 +59,9 @@ def main():
     if mode in ("fwd", "both"):
         t = timeit(lambda: ops.conv_fwd(d, x, packed, y, ws=ws))
         print("fwd   B%d H%d %d->%d k%d pad%d: %8.1f us  %7.1f TF" % (B, H, cin, cout, k, pad, t * 1e6, flops / t / 1e12))
+        from cvae_gan_amd._lib import lib
+        if hasattr(lib, "cvg_debug_timing_dump"):      # only in instrumented experiment builds
+            lib.cvg_debug_timing_dump()
     if mode in ("wgrad", "both"):
         t = timeit(lambda: ops.conv_wgrad(d, x, dy, dy.shape[1], wm, gw, ws))
         print("wgrad B%d H%d %d->%d k%d pad%d: %8.1f us  %7.1f TF" % (B, H, cin, cout, k, pad, t * 1e6, flops / t / 1e12))
