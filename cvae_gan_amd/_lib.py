@@ -87,6 +87,10 @@ def _load():
         "cvg_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
         "cvg_nhwc_to_nchw": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
         "cvg_nchw_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+        "cvg_gan_d_head": (C.c_int, [vp, i32, i32, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
+        "cvg_gan_c_head": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
+        "cvg_gan_feature_match": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
+        "cvg_axpy_f32": (C.c_int, [vp, vp, f32, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree

@@ -232,6 +232,152 @@ __global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, c
     }
 }
 
+// ---- heads and losses of the adversarial extension (discriminator / classifier on the encoder trunk)
+// Rows are samples, F trunk features per row (row pitch ld >= F, padding columns written as 0).
+// Everything is sized for a few thousand rows and F, y <= 1024: one wave or block per row, fixed
+// summation orders, no atomics.
+
+// Discriminator head: logit = <h, w> + b, BCE-with-logits against 1 for rows < n_real, 0 after.
+template <typename T>
+__global__ void __launch_bounds__(256) d_head_rows(const T* __restrict__ h, int ld, const float* __restrict__ w,
+                                                   const float* __restrict__ b, int M, int F, int n_real, float gscale,
+                                                   float* __restrict__ dlogit, float* __restrict__ loss_row,
+                                                   T* __restrict__ dh) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float acc = 0.f;
+    for (int j = lane; j < F; j += 64) acc += to_f32(h[(size_t)row * ld + j]) * w[j];
+    const float l = wave_sum(acc) + b[0];
+    const float t = row < n_real ? 1.f : 0.f;
+    const float sg = 1.f / (1.f + expf(-l));
+    const float dl = (sg - t) * gscale / (float)M;
+    if (lane == 0) {
+        loss_row[row] = fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l)));
+        dlogit[row] = dl;
+    }
+    for (int j = lane; j < ld; j += 64) dh[(size_t)row * ld + j] = from_f32<T>(j < F ? dl * w[j] : 0.f);
+}
+template <typename T>
+__global__ void __launch_bounds__(1024) d_head_reduce(const T* __restrict__ h, int ld, const float* __restrict__ dlogit,
+                                                      const float* __restrict__ loss_row, int M, int F,
+                                                      float* __restrict__ dw, float* __restrict__ db,
+                                                      float* __restrict__ loss_out) {
+    const int j = threadIdx.x;
+    if (j < F) {
+        float s = 0.f;
+        for (int r = 0; r < M; ++r) s += dlogit[r] * to_f32(h[(size_t)r * ld + j]);
+        dw[j] = s;
+    } else if (j == F) {
+        float s = 0.f;
+        for (int r = 0; r < M; ++r) s += dlogit[r];
+        db[0] = s;
+    } else if (j == F + 1) {
+        float s = 0.f;
+        for (int r = 0; r < M; ++r) s += loss_row[r];
+        loss_out[0] = s / (float)M;
+    }
+}
+
+// Classifier head: logits = h W^T + b ([y][F] weights), softmax cross-entropy over the first n_real
+// rows (mean); the other rows contribute nothing and get a zero gradient.
+template <typename T>
+__global__ void __launch_bounds__(256) c_head_rows(const T* __restrict__ h, int ld, const float* __restrict__ W,
+                                                   const float* __restrict__ b, const int* __restrict__ labels, int M,
+                                                   int F, int y, int n_real, float gscale, float* __restrict__ dlogits,
+                                                   float* __restrict__ loss_row, T* __restrict__ dh) {
+    __shared__ float hrow[1024], lg[1024], red[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bool real = row < n_real;
+    for (int j = tid; j < F; j += 256) hrow[j] = to_f32(h[(size_t)row * ld + j]);
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (int c = tid; c < y; c += 256) {
+        float a = b[c];
+        for (int j = 0; j < F; ++j) a += hrow[j] * W[(size_t)c * F + j];
+        lg[c] = a;
+        mx = fmaxf(mx, a);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float se = 0.f;
+    for (int c = tid; c < y; c += 256) se += expf(lg[c] - mx);
+    red[tid] = se;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    se = red[0];
+    const int lab = real ? labels[row] : 0;
+    const float lab_logit = lg[lab];
+    const float k = gscale / (float)n_real;
+    __syncthreads();                                  // everyone has read lg before it is overwritten
+    for (int c = tid; c < y; c += 256) {
+        const float pc = expf(lg[c] - mx) / se;
+        const float d = real ? (pc - (c == lab ? 1.f : 0.f)) * k : 0.f;
+        dlogits[(size_t)row * y + c] = d;
+        lg[c] = d;
+    }
+    if (tid == 0) loss_row[row] = real ? (logf(se) + mx - lab_logit) : 0.f;
+    __syncthreads();
+    for (int j = tid; j < ld; j += 256) {
+        float a = 0.f;
+        if (real && j < F)
+            for (int c = 0; c < y; ++c) a += lg[c] * W[(size_t)c * F + j];
+        dh[(size_t)row * ld + j] = from_f32<T>(a);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(1024) c_head_reduce(const T* __restrict__ h, int ld, const float* __restrict__ dlogits,
+                                                      const float* __restrict__ loss_row, int F, int y, int n_real,
+                                                      float* __restrict__ dW, float* __restrict__ db,
+                                                      float* __restrict__ loss_out) {
+    const int c = blockIdx.x, j = threadIdx.x;
+    if (j < F) {
+        float s = 0.f;
+        for (int r = 0; r < n_real; ++r) s += dlogits[(size_t)r * y + c] * to_f32(h[(size_t)r * ld + j]);
+        dW[(size_t)c * F + j] = s;
+    } else if (j == F) {
+        float s = 0.f;
+        for (int r = 0; r < n_real; ++r) s += dlogits[(size_t)r * y + c];
+        db[c] = s;
+    } else if (j == F + 1 && c == 0) {
+        float s = 0.f;
+        for (int r = 0; r < n_real; ++r) s += loss_row[r];
+        loss_out[0] = s / (float)n_real;
+    }
+}
+
+// Mean feature matching: loss = 1/2 |mean(h[r0:r1]) - mean(h[f0:f1])|^2; the gradient goes to the
+// rows [f0, f1) only (the first mean is a constant target), every other row of dh is zeroed.
+template <typename T>
+__global__ void __launch_bounds__(1024) feature_match(const T* __restrict__ h, int ld, int M, int F, int r0, int r1,
+                                                      int f0, int f1, float gscale, float* __restrict__ loss_out,
+                                                      T* __restrict__ dh) {
+    __shared__ float red[1024];
+    const int j = threadIdx.x;
+    float d = 0.f;
+    if (j < F) {
+        float a = 0.f, c = 0.f;
+        for (int r = r0; r < r1; ++r) a += to_f32(h[(size_t)r * ld + j]);
+        for (int r = f0; r < f1; ++r) c += to_f32(h[(size_t)r * ld + j]);
+        d = c / (float)(f1 - f0) - a / (float)(r1 - r0);
+    }
+    red[j] = d * d;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (j < o) red[j] += red[j + o]; __syncthreads(); }
+    if (j == 0) loss_out[0] = 0.5f * red[0];
+    if (j < ld) {
+        const float g = d * gscale / (float)(f1 - f0);
+        for (int r = 0; r < M; ++r) dh[(size_t)r * ld + j] = from_f32<T>((r >= f0 && r < f1) ? g : 0.f);
+    }
+}
+
+__global__ void axpy_f32(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+
 // ---- small vector helpers -----------------------------------------------------------------
 __global__ void permute_f32(const float* in, float* out, int n, int d, int a, int b) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1055,6 +1201,52 @@ int cvg_nchw_to_nhwc(const float* in, void* out, int32_t dtype, int32_t B, int32
                      cvg_stream stream) {
     CVG_CHECK(in && out && ld >= C, "nchw_to_nhwc: bad args");
     DISPATCH(dtype, nchw_to_nhwc<T><<<grid1((int64_t)B * HW * ld), 256, 0, (hipStream_t)stream>>>(in, (T*)out, B, HW, C, ld));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_gan_d_head(const void* h, int32_t dtype, int32_t ld, const float* w, const float* b, int32_t M, int32_t F,
+                   int32_t n_real, float grad_scale, float* dw, float* db, float* loss, void* dh, float* ws,
+                   cvg_stream stream) {
+    CVG_CHECK(h && w && b && dw && db && loss && dh && ws && M > 0 && F > 0 && F <= 1022 && ld >= F && n_real >= 0 &&
+              n_real <= M, "gan_d_head: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    float* dlogit = ws;
+    float* loss_row = ws + M;
+    DISPATCH(dtype, d_head_rows<T><<<grid1(M, 4), 256, 0, s>>>((const T*)h, ld, w, b, M, F, n_real, grad_scale, dlogit,
+                                                              loss_row, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    DISPATCH(dtype, d_head_reduce<T><<<1, 1024, 0, s>>>((const T*)h, ld, dlogit, loss_row, M, F, dw, db, loss));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_gan_c_head(const void* h, int32_t dtype, int32_t ld, const float* W, const float* b, const int32_t* labels,
+                   int32_t M, int32_t F, int32_t y, int32_t n_real, float grad_scale, float* dW, float* db, float* loss,
+                   void* dh, float* ws, cvg_stream stream) {
+    CVG_CHECK(h && W && b && labels && dW && db && loss && dh && ws && M > 0 && F > 0 && F <= 1022 && y > 0 && y <= 1024 &&
+              ld >= F && n_real > 0 && n_real <= M, "gan_c_head: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    float* dlogits = ws;
+    float* loss_row = ws + (size_t)M * y;
+    DISPATCH(dtype, c_head_rows<T><<<M, 256, 0, s>>>((const T*)h, ld, W, b, labels, M, F, y, n_real, grad_scale, dlogits,
+                                                    loss_row, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    DISPATCH(dtype, c_head_reduce<T><<<y, 1024, 0, s>>>((const T*)h, ld, dlogits, loss_row, F, y, n_real, dW, db, loss));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_gan_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t M, int32_t F, int32_t r0, int32_t r1,
+                          int32_t f0, int32_t f1, float grad_scale, float* loss, void* dh, cvg_stream stream) {
+    CVG_CHECK(h && loss && dh && M > 0 && F > 0 && ld >= F && ld <= 1024 && 0 <= r0 && r0 < r1 && r1 <= M && 0 <= f0 &&
+              f0 < f1 && f1 <= M, "gan_feature_match: bad args");
+    DISPATCH(dtype, feature_match<T><<<1, 1024, 0, (hipStream_t)stream>>>((const T*)h, ld, M, F, r0, r1, f0, f1,
+                                                                          grad_scale, loss, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_axpy_f32(float* y, const float* x, float alpha, int64_t n, cvg_stream stream) {
+    CVG_CHECK(y && x && n > 0, "axpy: bad args");
+    axpy_f32<<<grid1(n), 256, 0, (hipStream_t)stream>>>(y, x, alpha, n);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -132,12 +132,17 @@ def init_state(P, y_dim, z_dim, seed=0, n_stage=4, ngf=64):
     return out[0], out[1]
 
 
-def arena_layout(P, y_dim, z_dim, n_stage=4, ngf=64):
+def arena_layout(P, y_dim, z_dim, n_stage=4, ngf=64, parts="both", extra=None):
     """Flat f32 arena shared by parameters, gradients and AdamW moments.  Tensors are placed in
     the order in which backward finishes their gradients (decoder tail first, encoder stem
-    last), so that contiguous ranges can be all-reduced while backward is still running."""
+    last), so that contiguous ranges can be all-reduced while backward is still running.
+    parts="encoder" leaves the decoder out (a critic is the trunk alone); extra: {name: shape} of
+    further trainable tensors (heads), placed first."""
     enc_s, dec_s = param_shapes(P, y_dim, z_dim, n_stage, ngf)
+    if parts == "encoder":
+        dec_s = OrderedDict()
     shapes = OrderedDict()
+    shapes.update(extra or {})
     shapes.update(enc_s)
     shapes.update(dec_s)
     trainable = [k for k in shapes if not is_buffer(k)]
@@ -156,7 +161,7 @@ def arena_layout(P, y_dim, z_dim, n_stage=4, ngf=64):
             return 3 - int(k.split(".fc.")[1].split(".")[0])
         return 100 - int(k[len(EP) + 5:].split(".")[0])
 
-    order = sorted(dec_tr, key=dec_rank) + sorted(enc_tr, key=enc_rank)
+    order = [k for k in (extra or {})] + sorted(dec_tr, key=dec_rank) + sorted(enc_tr, key=enc_rank)
     offs, n = {}, 0
     for k in order:
         offs[k] = n
@@ -220,9 +225,14 @@ class _Gemm:
 
 class Engine:
     def __init__(self, pix_dim, y_dim, z_dim, batch, dtype=torch.bfloat16, ngf=64, n_stage=4,
-                 device="cuda", seed=0, state=None, share=None):
+                 device="cuda", seed=0, state=None, share=None, parts="both", extra_params=None,
+                 own_grads=False, stem_input_grad=False):
         """share: another Engine of the same network; this one then aliases its parameter,
-        gradient and optimiser arenas and BatchNorm buffers (only the batch size differs)."""
+        gradient and optimiser arenas and BatchNorm buffers (only the batch size differs);
+        own_grads gives it a gradient arena of its own all the same (two passes over shared
+        weights whose gradients are added afterwards).  parts="encoder": the trunk alone
+        (y_dim may then be 0: no label planes); extra_params: {name: shape} of further trainable
+        tensors in the same arenas; stem_input_grad: also plan the gradient w.r.t. the image."""
         assert pix_dim % (2 ** n_stage) == 0, "pix_dim must be a multiple of %d" % (2 ** n_stage)
         assert z_dim % 4 == 0, "z_dim must be a multiple of 4 (channel vectors are 8 wide)"
         assert ngf % 8 == 0 and (ngf & (ngf - 1)) == 0, "ngf must be a power of two >= 8"
@@ -238,10 +248,20 @@ class Engine:
         self.step_count = 0
         self.training = True
         self.grad_ready = None      # callable(stage) -> None, see cvae_gan_amd/ddp.py
-        self._share = share
+        self._frozen = False
+        self._share, self._own_grads = share, own_grads
+        self.parts, self._extra = parts, OrderedDict(extra_params or {})
+        self.stem_input_grad = stem_input_grad
+        self.dec = None
         self._build_params(seed, state)
         self._build_encoder()
-        self._build_decoder()
+        if parts == "both":
+            self._build_decoder()
+        else:
+            self.losses = self._f(4)
+            self.step_dev = torch.zeros(1, dtype=torch.long, device=self.device)
+            self.seed_dev = torch.zeros(1, dtype=torch.long, device=self.device)
+            self.bc_dev = self._f(2)
         self._build_workspaces()
         if share is not None:        # one optimiser state for all engines of the network
             self.step_dev, self.bc_dev = share.step_dev, share.bc_dev
@@ -259,7 +279,7 @@ class Engine:
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self, seed, state):
-        lay = arena_layout(self.P, self.y, self.z, self.n_stage, self.ngf)
+        lay = arena_layout(self.P, self.y, self.z, self.n_stage, self.ngf, self.parts, self._extra)
         self.enc_keys, self.dec_keys, self.shapes = lay["enc_keys"], lay["dec_keys"], lay["shapes"]
         self.arena_order, self.arena_offsets, self.arena_numel = lay["order"], lay["offsets"], lay["numel"]
         shapes, order, offs, n = self.shapes, self.arena_order, self.arena_offsets, self.arena_numel
@@ -269,6 +289,10 @@ class Engine:
             assert (sh.P, sh.y, sh.z, sh.ngf, sh.n_stage) == (self.P, self.y, self.z, self.ngf, self.n_stage)
             self.p_arena, self.g_arena, self.m_arena, self.v_arena = sh.p_arena, sh.g_arena, sh.m_arena, sh.v_arena
             self.params, self.grads, self.buffers, self._vers = sh.params, sh.grads, sh.buffers, sh._vers
+            if self._own_grads:
+                self.g_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+                self.grads = OrderedDict((k, self.g_arena[offs[k]:offs[k] + v.numel()].view(v.shape))
+                                         for k, v in sh.grads.items())
             return
         self._vers = [0]
         self.p_arena = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -289,7 +313,8 @@ class Engine:
         if state is None:
             e, d = init_state(self.P, self.y, self.z, seed, self.n_stage, self.ngf)
             state = OrderedDict(e)
-            state.update(d)
+            if self.parts == "both":
+                state.update(d)
         self.load_state(state)
 
     def load_state(self, state):
@@ -361,7 +386,16 @@ class Engine:
                           _wmap(1, (3 + self.y) * 49, 0, 4, 1, 49, ngf, 3, 56, tap_mode=2, table=table),
                           EP + "conv.1.weight")
         e["xpad"] = self._t(B, Hp, Wp, 4)
-        e["cbias"] = self._f(self.y, ngf)
+        e["cbias"] = self._f(self.y, ngf) if self.y > 0 else None
+        if self.stem_input_grad:
+            # gradient w.r.t. the reflection-padded image = full correlation of d_s0 with the
+            # flipped kernel (zero padding 6), channels 3.. dropped; folded back by cvg_reflect_fold
+            e["stem_dg"] = _Gemm(self, _desc(T, B, P, P, ngf, P + 6, P + 6, 8, 7, 49, off=(-6, -6)),
+                                 _wmap(1, 49, 0, ngf, 1, (3 + self.y) * 49, 3, ngf, 49, tap_mode=1),
+                                 EP + "conv.1.weight")
+            e["d_xp"] = self._t(B * (P + 6) * (P + 6), 8)
+            e["d_x8"] = self._t(B * P * P, 8)
+            e["d_img"] = self._f(B, 3, P, P)
         e["s0"] = self._t(B * P * P, ngf)
         e["a0"] = self._t(B * P * P, ngf)
         e["st0"] = self._f(2, ngf)
@@ -504,11 +538,14 @@ class Engine:
         for desc in self._wgrad_descs:
             wg = max(wg, ops.conv_wgrad_workspace(desc))
         self.ws = torch.zeros(max(wg, self._ws_bytes, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
-        max_c = max(self.ngf * 8, self.dec["nout"], 4 * self.z, self.dec["F8"])
+        max_c = max(self.ngf * 8, 4 * self.z)
+        if self.dec is not None:
+            max_c = max(max_c, self.dec["nout"], self.dec["F8"])
         self.red_ws = torch.zeros(2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
         # the weight-gradient branch of backward runs on a side stream with workspaces of its own
         self.ws_side = torch.zeros(max(wg, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
         self.red_ws_side = torch.zeros_like(self.red_ws)
+        self._bn_scratch = (self._f(max_c), self._f(max_c))
 
     # ------------------------------------------------------------------ helpers
     def pack_weights(self, force=False):
@@ -518,11 +555,13 @@ class Engine:
             self._pack_batch = ops.PackBatch([(g.desc, g.wmap, self.params[g.key], g.w) for g in self._gemms],
                                              self.device)
         self._pack_batch.run()
-        ops.label_bias(self.params[EP + "conv.1.weight"], self.enc["cbias"], self.ngf, self.y)
+        if self.y > 0:
+            ops.label_bias(self.params[EP + "conv.1.weight"], self.enc["cbias"], self.ngf, self.y)
         d = self.dec
-        ops.permute_f32(self.params[DP + "fc.0.bias"], d["bias0"], d["F"])
-        ops.permute_f32(self.params[DP + "fc.3.bias"], d["bias3"], d["nout"], d["C0"], 1, self.s * self.s)
-        ops.permute_f32(self.params[d["tail_key"] + "bias"], d["tail_bias"], 3)
+        if d is not None:
+            ops.permute_f32(self.params[DP + "fc.0.bias"], d["bias0"], d["F"])
+            ops.permute_f32(self.params[DP + "fc.3.bias"], d["bias3"], d["nout"], d["C0"], 1, self.s * self.s)
+            ops.permute_f32(self.params[d["tail_key"] + "bias"], d["tail_bias"], 3)
         self._packed_version = self._param_version
 
     def _bn(self, x, res, y, M, C, stats, prefix):
@@ -536,8 +575,11 @@ class Engine:
 
     def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix):
         """y=None for a BatchNorm without a residual input: the gate is recomputed from x."""
-        ops.bn_act_bwd(dy, y, x, dx, M, C, stats, self.params[prefix + ".weight"],
-                       self.grads[prefix + ".weight"], self.grads[prefix + ".bias"], self.red_ws,
+        if self._frozen:        # parameters are constants in this pass: dgamma / dbeta only serve dx
+            dg, db = self._bn_scratch[0][:C], self._bn_scratch[1][:C]
+        else:
+            dg, db = self.grads[prefix + ".weight"], self.grads[prefix + ".bias"]
+        ops.bn_act_bwd(dy, y, x, dx, M, C, stats, self.params[prefix + ".weight"], dg, db, self.red_ws,
                        beta=self.params[prefix + ".bias"])
 
     def _ready(self, stage):
@@ -549,6 +591,8 @@ class Engine:
         ops.conv_fwd(g.desc, x, g.w, y, bias=bias, ws=self.ws, **kw)
 
     def _wgrad(self, g, x, dy, dy_ld):
+        if self._frozen:
+            return
         ops.conv_wgrad(g.desc, x, dy, dy_ld, g.wmap, self.grads[g.key], self.ws_side)
 
     @contextlib.contextmanager
@@ -581,10 +625,11 @@ class Engine:
         """x: f32 NCHW [B,3,P,P] on the device; labels: int32 [B].  Returns h [B, 2z]."""
         e, B, P, ngf = self.enc, self.B, self.P, self.ngf
         self.pack_weights()
-        e["labels"].copy_(labels)
+        if self.y > 0:
+            e["labels"].copy_(labels)
         ops.pack_image(x, e["xpad"], B, P)
         self._fwd(e["stem"], e["xpad"], e["s0"], bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],
-                  labels=e["labels"])
+                  labels=e["labels"] if self.y > 0 else None)
         self._bn(e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2")
         xin = e["a0"]
         for blk in e["blocks"]:
@@ -601,17 +646,30 @@ class Engine:
         self._fwd(e["fc3"], e["f1"], e["h"], bias=self.params[EP + "fc.3.bias"])
         return e["h"]
 
-    def enc_backward(self, dh):
+    def enc_backward(self, dh, param_grads=True, input_grad=False):
+        """param_grads=False: the parameters are constants in this pass (a critic judging the
+        generator): no weight / bias gradients are produced and self.grads is left alone.
+        input_grad=True (needs stem_input_grad at construction): also returns dL/dx as f32 NCHW."""
+        self._frozen = not param_grads
+        try:
+            return self._enc_backward(dh, input_grad)
+        finally:
+            self._frozen = False
+
+    def _enc_backward(self, dh, input_grad):
         e, B, P, ngf = self.enc, self.B, self.P, self.ngf
+        frozen = self._frozen
         last = e["blocks"][-1]
         with self._branch():
             self._wgrad(e["fc3"], e["f1"], dh, e["nz"])
-            ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws_side)
+            if not frozen:
+                ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws_side)
         self._fwd(e["fc3_dg"], dh, e["d_f1"])
         self._bn_bwd(e["d_f1"], None, e["f0"], e["d_f0"], B, e["fcd"], e["stf"], EP + "fc.1")
         with self._branch():
             self._wgrad(e["fc0"], last["out"], e["d_f0"], e["fcd"])
-            ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws_side)
+            if not frozen:
+                ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws_side)
         self._fwd(e["fc0_dg"], e["d_f0"], last["d_out"])
         self._ready("enc.head")
         for i in range(len(e["blocks"]) - 1, -1, -1):
@@ -634,10 +692,18 @@ class Engine:
         self._bn_bwd(e["d_a0"], None, e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
         with self._branch():
             self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
-            ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
-                               self.grads[EP + "conv.1.bias"], self.red_ws_side)
+            if not frozen:
+                ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
+                                   self.grads[EP + "conv.1.bias"], self.red_ws_side)
+        d_img = None
+        if input_grad:
+            self._fwd(e["stem_dg"], e["d_s0"], e["d_xp"])
+            ops.reflect_fold(e["d_xp"], e["d_x8"], B, P, P, 8, 3)
+            ops.nhwc_to_nchw(e["d_x8"], e["d_img"], B, P * P, 3, 8)
+            d_img = e["d_img"]
         self._ready("enc.stem")
         self._join()
+        return d_img
 
     # ------------------------------------------------------------------ sampler
     def sample(self, h, eps, batch_size):

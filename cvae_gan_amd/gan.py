@@ -1,0 +1,143 @@
+"""Adversarial extension of the train step: CVAE-GAN (arXiv 1703.10155, the paper the reference's
+README.md:3 names).  The reference repository itself contains no discriminator or classifier, so
+nothing here has reference code to be checked against; the checker is oracle/gan_cpu.py, a PyTorch
+autograd restatement of the same losses (parity unpinned).
+
+Networks.  Encoder E and generator G are the CVAE's encoder and decoder (cvae_gan_amd.engine.Engine).
+Discriminator D and classifier C are the same ResNetEncoder trunk (models/networks.py:164-196) without
+label planes, with F output features, followed by one linear head (F -> 1, F -> y).
+
+One step, for real images x with labels c, eps for the sampler and prior draws (z_p, c_p):
+    x_f = G(E(x, c), c)            reconstruction            x_p = G(z_p, c_p)      sample
+    D and C each see ONE joint batch [x | x_f | x_p] (BatchNorm statistics over all 3B rows)
+    L_D  = BCE(D(x), 1) + BCE(D(x_f), 0) + BCE(D(x_p), 0)      (mean over the 3B rows)  -> D
+    L_C  = CE(C(x), c)                                                                 -> C
+    L_GD = 1/2 |mean f_D(x) - mean f_D(x_p)|^2,  L_GC likewise with f_C   (mean feature matching;
+           f = the trunk output; the real-image mean is a constant target)             -> G (and E)
+    L_VAE = KL + LL as in models/cvae.py:137-140                                        -> E, G
+E and G minimise L_VAE + lam_gd * L_GD + lam_gc * L_GC with D and C held constant; the image gradients
+of the matching losses reach x_p and, through the joint BatchNorm statistics, x_f.  The paper's
+per-class feature centres and pairwise feature reconstruction terms are not included.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .engine import Engine
+
+
+class Critic:
+    """ResNetEncoder trunk + linear head over a joint batch of M rows."""
+
+    def __init__(self, pix_dim, n_out, features, rows, dtype=torch.bfloat16, ngf=64, n_stage=4, device="cuda", seed=0):
+        assert features % 8 == 0, "trunk features must be a multiple of 8"
+        self.F, self.n_out, self.M = features, n_out, rows
+        extra = OrderedDict([("head.weight", (n_out, features)), ("head.bias", (n_out,))])
+        self.trunk = Engine(pix_dim, 0, features // 2, rows, dtype=dtype, ngf=ngf, n_stage=n_stage, device=device,
+                            seed=seed, parts="encoder", extra_params=extra, stem_input_grad=True)
+        t = self.trunk
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():       # init_weights('kaiming') semantics for the head (networks.py:283-304)
+            t.params["head.weight"].copy_(torch.randn(n_out, features, generator=g) * (2.0 / features) ** 0.5)
+            t.params["head.bias"].zero_()
+        self.dh_own = torch.zeros(rows, features, dtype=dtype, device=t.device)     # from the critic's own loss
+        self.dh_gen = torch.zeros(rows, features, dtype=dtype, device=t.device)     # from the matching loss
+        self.ws = torch.zeros(rows * max(n_out, 1) + 2 * rows + 16, dtype=torch.float32, device=t.device)
+        self.losses = torch.zeros(2, dtype=torch.float32, device=t.device)          # [own, matching]
+
+    @property
+    def params(self):
+        return self.trunk.params
+
+    @property
+    def grads(self):
+        return self.trunk.grads
+
+    def forward(self, x3):
+        return self.trunk.enc_forward(x3, None)
+
+    def backward_own(self):
+        self.trunk.enc_backward(self.dh_own)
+
+    def backward_generator(self):
+        """dL_match / d(images) with this critic's parameters held constant: f32 [M,3,P,P]."""
+        return self.trunk.enc_backward(self.dh_gen, param_grads=False, input_grad=True)
+
+    def adamw_step(self, lr):
+        self.trunk.adamw_step(lr)
+
+
+class CVAEGAN:
+    def __init__(self, pix_dim, y_dim, z_dim, batch, dtype=torch.bfloat16, ngf=64, n_stage=4, features=64,
+                 lam_gd=1e-3, lam_gc=1e-3, device="cuda", seed=0, state=None):
+        self.B, self.P, self.y, self.z = batch, pix_dim, y_dim, z_dim
+        self.lam_gd, self.lam_gc = lam_gd, lam_gc
+        kw = dict(dtype=dtype, ngf=ngf, n_stage=n_stage, device=device)
+        self.vae = Engine(pix_dim, y_dim, z_dim, batch, seed=seed, state=state, **kw)
+        # second pass through the generator (the prior samples): same weights, gradients of its own
+        self.gen2 = Engine(pix_dim, y_dim, z_dim, batch, share=self.vae, own_grads=True, **kw)
+        self.D = Critic(pix_dim, 1, features, 3 * batch, seed=seed + 101, **kw)
+        self.C = Critic(pix_dim, y_dim, features, 3 * batch, seed=seed + 202, **kw)
+        dev = self.vae.device
+        self.x3 = torch.zeros(3 * batch, 3, pix_dim, pix_dim, dtype=torch.float32, device=dev)
+        self.labels_dev = torch.zeros(3 * batch, dtype=torch.int32, device=dev)
+
+    def forward_backward(self, x, labels, eps, z_p, y_p, batch_size):
+        """x f32 NCHW [B,3,P,P]; labels int32 [B]; eps, z_p f32 [B,z]; y_p one-hot f32 [B,y].  The two
+        dropout masks are the ones last set on self.vae / self.gen2.  Gradients land in the four
+        networks' arenas; losses: self.vae.losses[0:2] = KL, LL; self.D.losses / self.C.losses =
+        [own loss, matching loss]."""
+        A, G2, D, C, B = self.vae, self.gen2, self.D, self.C, self.B
+        # ---- E, G forward
+        h = A.enc_forward(x, labels)
+        zin = A.sample(h, eps, batch_size)
+        dec_f = A.dec_forward(zin, A.dec["mask"])
+        dec_p = G2.dec_forward(G2.set_decoder_input(z_p, y_p), G2.dec["mask"])
+        self.x3[:B].copy_(x)
+        self.x3[B:2 * B].copy_(dec_f)
+        self.x3[2 * B:].copy_(dec_p)
+        self.labels_dev[:B].copy_(labels)
+        # ---- critics: own losses (parameter gradients), then the matching losses (image gradients)
+        M, F = 3 * B, D.F
+        hD = D.forward(self.x3)
+        ops.gan_d_head(hD, F, D.params["head.weight"], D.params["head.bias"], M, F, B, 1.0, D.grads["head.weight"],
+                       D.grads["head.bias"], D.losses[0:1], D.dh_own, D.ws)
+        ops.gan_feature_match(hD, F, M, F, 0, B, 2 * B, M, self.lam_gd, D.losses[1:2], D.dh_gen)
+        D.backward_own()
+        dimg_d = D.backward_generator()
+        hC = C.forward(self.x3)
+        ops.gan_c_head(hC, F, C.params["head.weight"], C.params["head.bias"], self.labels_dev, M, F, self.y, B, 1.0,
+                       C.grads["head.weight"], C.grads["head.bias"], C.losses[0:1], C.dh_own, C.ws)
+        ops.gan_feature_match(hC, F, M, F, 0, B, 2 * B, M, self.lam_gc, C.losses[1:2], C.dh_gen)
+        C.backward_own()
+        dimg_c = C.backward_generator()
+        # ---- generator / encoder backward
+        d = A.dec
+        ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, 1.0, A.red_ws)
+        ops.axpy(d["d_dec"], dimg_d[B:2 * B], 1.0)
+        ops.axpy(d["d_dec"], dimg_c[B:2 * B], 1.0)
+        G2.dec["d_dec"].copy_(dimg_d[2 * B:])
+        ops.axpy(G2.dec["d_dec"], dimg_c[2 * B:], 1.0)
+        dzin = A.dec_backward(d["d_dec"], d["mask"])
+        A.sample_backward(dzin, eps, None, None, 1.0, batch_size)
+        A.enc_backward(A.enc["dh"])
+        G2.dec_backward(G2.dec["d_dec"], G2.dec["mask"])
+        ops.axpy(A.g_arena, G2.g_arena, 1.0)
+        return dec_f, dec_p
+
+    def adamw_step(self, lr):
+        self.vae.adamw_step(lr)
+        self.D.adamw_step(lr)
+        self.C.adamw_step(lr)
+
+    def train_step(self, x, labels, eps, z_p, y_p, batch_size, lr):
+        out = self.forward_backward(x, labels, eps, z_p, y_p, batch_size)
+        self.adamw_step(lr)
+        return out
+
+    def read_losses(self):
+        kl, ll = self.vae.losses[:2].tolist()
+        ld, lgd = self.D.losses.tolist()
+        lc, lgc = self.C.losses.tolist()
+        return dict(KL=kl, LL=ll, D=ld, C=lc, GD=lgd, GC=lgc)

@@ -231,3 +231,24 @@ def nhwc_to_nchw(src, out, B, HW, C_, ld):
 
 def nchw_to_nhwc(src, out, B, HW, C_, ld):
     check(lib.cvg_nchw_to_nhwc(ptr(src), ptr(out), dt(out), B, HW, C_, ld, stream()))
+
+
+# ---- adversarial extension (discriminator / classifier heads and losses) -------------------
+def gan_d_head(h, ld, w, b, M, F, n_real, grad_scale, dw, db, loss, dh, ws):
+    check(lib.cvg_gan_d_head(ptr(h), dt(h), ld, ptr(w), ptr(b), M, F, n_real, grad_scale, ptr(dw), ptr(db), ptr(loss),
+                             ptr(dh), ptr(ws), stream()))
+
+
+def gan_c_head(h, ld, W, b, labels, M, F, y, n_real, grad_scale, dW, db, loss, dh, ws):
+    check(lib.cvg_gan_c_head(ptr(h), dt(h), ld, ptr(W), ptr(b), ptr(labels), M, F, y, n_real, grad_scale, ptr(dW),
+                             ptr(db), ptr(loss), ptr(dh), ptr(ws), stream()))
+
+
+def gan_feature_match(h, ld, M, F, r0, r1, f0, f1, grad_scale, loss, dh):
+    check(lib.cvg_gan_feature_match(ptr(h), dt(h), ld, M, F, r0, r1, f0, f1, grad_scale, ptr(loss), ptr(dh), stream()))
+
+
+def axpy(y, x, alpha, n=None):
+    """y += alpha * x (f32)."""
+    assert y.dtype == torch.float32 and x.dtype == torch.float32
+    check(lib.cvg_axpy_f32(ptr(y), ptr(x), alpha, y.numel() if n is None else n, stream()))

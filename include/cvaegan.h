@@ -290,6 +290,31 @@ int cvg_nhwc_to_nchw(const void* in, int32_t dtype, float* out, int32_t B, int32
 int cvg_nchw_to_nhwc(const float* in, void* out, int32_t dtype, int32_t B, int32_t HW, int32_t C,
                      int32_t ld, cvg_stream s);
 
+/* ---- adversarial extension (CVAE-GAN, arXiv 1703.10155, named by the reference's README.md:3;
+ * the reference itself holds no discriminator / classifier code).  Discriminator and classifier
+ * are the encoder trunk (ResNetEncoder, networks.py:164-196, without label planes) followed by
+ * one linear head on its F-dimensional output h [M][ld] (dtype).  ws: float scratch.           */
+/* Discriminator head + BCEWithLogits: logit = <h_row, w> + b, target 1 for rows < n_real, 0 after;
+ * loss = mean over the M rows; dh = grad_scale * dloss/dh (padding columns 0), dw [F], db [1].
+ * ws >= 2*M floats.                                                                              */
+int cvg_gan_d_head(const void* h, int32_t dtype, int32_t ld, const float* w, const float* b,
+                   int32_t M, int32_t F, int32_t n_real, float grad_scale,
+                   float* dw, float* db, float* loss, void* dh, float* ws, cvg_stream s);
+/* Classifier head + softmax cross-entropy over the first n_real rows (mean): W [y][F], b [y],
+ * labels int32 [>= n_real]; rows >= n_real get dh = 0.  ws >= M*y + M floats.                    */
+int cvg_gan_c_head(const void* h, int32_t dtype, int32_t ld, const float* W, const float* b,
+                   const int32_t* labels, int32_t M, int32_t F, int32_t y, int32_t n_real,
+                   float grad_scale, float* dW, float* db, float* loss, void* dh, float* ws,
+                   cvg_stream s);
+/* Mean feature matching: loss = 1/2 |mean(h[r0:r1]) - mean(h[f0:f1])|^2 with the first mean a
+ * constant target; dh rows [f0, f1) = grad_scale * (mean_f - mean_r) / (f1 - f0), other rows 0. */
+int cvg_gan_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t M, int32_t F,
+                          int32_t r0, int32_t r1, int32_t f0, int32_t f1, float grad_scale,
+                          float* loss, void* dh, cvg_stream s);
+/* y += alpha * x over n floats (gradient arenas of two passes over shared weights, image
+ * gradients arriving from several critics).                                                     */
+int cvg_axpy_f32(float* y, const float* x, float alpha, int64_t n, cvg_stream s);
+
 #ifdef __cplusplus
 }
 #endif
