@@ -76,8 +76,18 @@ class CVAE(object):
         self.trainset_loader = DataLoader(dataset=self.train_data, batch_size=args.batch_size, drop_last=True,
                                           shuffle=True, num_workers=getattr(args, "worker", 0), pin_memory=True)
 
-        self.engine = Engine(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
-                             device=self.device, seed=getattr(args, "seed", 0))
+        # --gan_type CVAEGAN (starter.py:31 declares the flag, the reference never reads it): the adversarial step of cvae_gan_amd/gan.py (discriminator + classifier next to the
+        # CVAE; no counterpart in the reference's trainer); self.engine stays the CVAE either way
+        self.gan = None
+        if getattr(args, "gan", False) or getattr(args, "gan_type", "VAE").upper() in ("CVAEGAN", "CVAE-GAN", "GAN"):
+            from .gan import CVAEGAN
+            self.gan = CVAEGAN(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
+                               device=self.device, seed=getattr(args, "seed", 0),
+                               lam_gd=getattr(args, "lam_gd", 1e-3), lam_gc=getattr(args, "lam_gc", 1e-3))
+            self.engine = self.gan.vae
+        else:
+            self.engine = Engine(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
+                                 device=self.device, seed=getattr(args, "seed", 0))
         self._sample_engine = None
         if getattr(args, "resume", False):
             try:
@@ -106,6 +116,9 @@ class CVAE(object):
         save_dir = check_folder(os.path.join(self.save_dir, self.model_dir))
         torch.save(self.engine.state_dict("encoder"), os.path.join(save_dir, self.dataset + "_encoder.pkl"))
         torch.save(self.engine.state_dict("decoder"), os.path.join(save_dir, self.dataset + "_decoder.pkl"))
+        if self.gan is not None:
+            torch.save(self.gan.D.trunk.state_dict("critic"), os.path.join(save_dir, self.dataset + "_discriminator.pkl"))
+            torch.save(self.gan.C.trunk.state_dict("critic"), os.path.join(save_dir, self.dataset + "_classifier.pkl"))
         with open(os.path.join(save_dir, self.dataset + "_history.pkl"), "wb") as f:
             pickle.dump(self.train_hist, f)
 
@@ -114,6 +127,10 @@ class CVAE(object):
         for half in ("encoder", "decoder"):
             sd = torch.load(base + "_%s.pkl" % half, map_location="cpu", weights_only=True)
             self.engine.load_state(sd)
+        if self.gan is not None:
+            for name, critic in (("discriminator", self.gan.D), ("classifier", self.gan.C)):
+                if os.path.exists(base + "_%s.pkl" % name):
+                    critic.trunk.load_state(torch.load(base + "_%s.pkl" % name, map_location="cpu", weights_only=True))
 
     # ------------------------------------------------------------------ training
     def _to_device(self, imgs, labels):
@@ -133,6 +150,11 @@ class CVAE(object):
         eng.training = True
         print("training start!!")
         eps = torch.empty(self.batch_size, self.z_dim, device=self.device)
+        if self.gan is not None:
+            hist.update(D_loss=[], C_loss=[])
+            z_p = torch.empty(self.batch_size, self.z_dim, device=self.device)
+            y_p = torch.zeros(self.batch_size, self.y_dim, device=self.device)
+            rows = torch.arange(self.batch_size, device=self.device)
         start_time = time.time()
         iters = 0
         for epoch in range(self.epoch):
@@ -141,10 +163,22 @@ class CVAE(object):
             for it, (x, cls) in enumerate(self.batches()):
                 eps.normal_()
                 eng.random_mask()
-                eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
+                if self.gan is not None:
+                    z_p.normal_()
+                    y_p.zero_()
+                    y_p[rows, torch.randint(0, self.y_dim, (self.batch_size,), device=self.device)] = 1
+                    self.gan.gen2.random_mask()
+                    self.gan.train_step(x, cls, eps, z_p, y_p, float(self.batch_size), self.lr)
+                else:
+                    eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
                 iters += 1
                 if (it + 1) % self.log_every == 0:
                     l = eng.read_losses()
+                    if self.gan is not None:
+                        gl = self.gan.read_losses()
+                        hist["D_loss"].append(gl["D"])
+                        hist["C_loss"].append(gl["C"])
+                        print("            D_loss: %.6f C_loss: %.6f GD: %.6f GC: %.6f" % (gl["D"], gl["C"], gl["GD"], gl["GC"]))
                     hist["VAE_loss"].append(l["VAE"])
                     hist["KL_loss"].append(l["KL"])
                     hist["LL_loss"].append(l["LL"])

@@ -332,7 +332,8 @@ class Engine:
 
     def state_dict(self, which):
         """'encoder' / 'decoder' checkpoint dict with the reference's keys, on the CPU."""
-        keys = self.enc_keys if which == "encoder" else self.dec_keys
+        keys = {"encoder": self.enc_keys, "decoder": self.dec_keys,
+                "critic": list(self._extra) + self.enc_keys}[which]      # critic: trunk + head
         out = OrderedDict()
         for k in keys:
             t = self.buffers[k] if is_buffer(k) else self.params[k]

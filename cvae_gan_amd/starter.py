@@ -32,6 +32,8 @@ def build_parser():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0: run the epochs)")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--lam_gd", type=float, default=1e-3, help="weight of the discriminator feature-matching loss")
+    p.add_argument("--lam_gc", type=float, default=1e-3, help="weight of the classifier feature-matching loss")
     return p
 
 

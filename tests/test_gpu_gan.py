@@ -88,3 +88,66 @@ def test_frozen_backward_leaves_parameter_gradients_alone():
     torch.cuda.synchronize()
     assert torch.equal(before, D.trunk.g_arena)
     assert dimg.shape == (3 * B, 3, P, P) and float(dimg.abs().max()) > 0
+
+
+def test_gan_trainer_runs_and_checkpoints(tmp_path):
+    """starter flag --gan_type CVAEGAN: the adversarial step runs inside the reference-shaped trainer
+    (bf16), the classifier learns the synthetic classes, all four checkpoints are written and a
+    second trainer resumes from them."""
+    import os
+    import numpy as np
+    from test_gpu_trainer import _args
+    from cvae_gan_amd.cvae import CVAE
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = CVAE(_args(tmp_path, epoch=3, gan_type="CVAEGAN"))
+    assert m.gan is not None and m.engine is m.gan.vae
+    m.train()
+    h = m.train_hist
+    assert all(np.isfinite(h["LL_loss"])) and all(np.isfinite(h["D_loss"])) and all(np.isfinite(h["C_loss"]))
+    assert np.mean(h["C_loss"][-3:]) < np.mean(h["C_loss"][:3])
+    d = os.path.join(m.save_dir, m.model_dir)
+    for name in ("encoder", "decoder", "discriminator", "classifier"):
+        assert os.path.exists(os.path.join(d, "Synth_%s.pkl" % name)), name
+    cl = torch.load(os.path.join(d, "Synth_classifier.pkl"), weights_only=True)
+    assert tuple(cl["head.weight"].shape) == (4, 64) and tuple(cl["encoder.module.conv.1.weight"].shape) == (64, 3, 7, 7)
+    m2 = CVAE(_args(tmp_path, resume=True, gan_type="CVAEGAN"))
+    for k, v in m.gan.C.trunk.state_dict("critic").items():
+        assert torch.equal(v, m2.gan.C.trunk.state_dict("critic")[k]), k
+
+
+def test_gan_step_bf16_tracks_f32():
+    """bf16 mode against the f32 mode of the same HIP path (c2 widths, batch 32: with fewer rows the
+    batch-statistics backward is too ill-conditioned to compare directions): losses within 5e-2
+    relative, cosine of the whole gradient arena of each network >= 0.96."""
+    from cvae_gan_amd.gan import CVAEGAN
+    P, y, z, B = 32, 10, 32, 32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(B, 3, P, P, device="cuda", generator=g) * 2 - 1
+    labels = torch.randint(0, y, (B,), device="cuda", generator=g, dtype=torch.int32)
+    eps = torch.randn(B, z, device="cuda", generator=g)
+    z_p = torch.randn(B, z, device="cuda", generator=g)
+    y_p = torch.nn.functional.one_hot(torch.randint(0, y, (B,), device="cuda", generator=g), y).float()
+    # the generator's weights are scaled by 0.55 on both sides, which brings its pre-tanh activations
+    # to O(1); at the untouched initialisation the tanh is saturated and gradient directions are
+    # dominated by rounding in either precision
+    from cvae_gan_amd.engine import init_state
+    e_sd, d_sd = init_state(P, y, z, seed=4)
+    state = dict(e_sd)
+    state.update({k: (v * 0.55 if k.endswith("weight") else v) for k, v in d_sd.items()})
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        net = CVAEGAN(P, y, z, B, dtype=dtype, lam_gd=0.1, lam_gc=0.1, seed=4, state=state)
+        net.vae.random_mask(7)
+        net.gen2.random_mask(8)
+        net.forward_backward(x, labels, eps, z_p, y_p, float(B))
+        torch.cuda.synchronize()
+        res[dtype] = (net.read_losses(), net.vae.g_arena.clone(), net.D.trunk.g_arena.clone(), net.C.trunk.g_arena.clone())
+    lf, lb = res[torch.float32][0], res[torch.bfloat16][0]
+    for k in ("KL", "LL", "D", "C"):
+        assert abs(lf[k] - lb[k]) <= 5e-2 * max(abs(lf[k]), 1e-3), (k, lf[k], lb[k])
+    for i, name in ((1, "E+G"), (2, "D"), (3, "C")):
+        a, b = res[torch.float32][i].double(), res[torch.bfloat16][i].double()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        print(name, "cosine", cos)
+        assert cos >= 0.96, (name, cos)
