@@ -54,8 +54,8 @@ class KernelTimer:
     """HIP-event brackets around every implicit-GEMM launch, on the stream they are launched on."""
 
     def __init__(self, eng):
-        self.eng, self.records = eng, []
-        self._fwd, self._wgrad = eng._fwd, eng._wgrad
+        self.eng, self.records, self.hbm = eng, [], []
+        self._fwd, self._wgrad, self._bn, self._bn_bwd = eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd
 
     def __enter__(self):
         eng = self.eng
@@ -74,11 +74,46 @@ class KernelTimer:
             b.record()
             self.records.append((self.kernel_name(g, "wgrad"), gemm_flops(g), a, b, g))
 
-        eng._fwd, eng._wgrad = fwd, wgrad
+        es = 2 if eng.dtype == torch.bfloat16 else 4
+
+        # HBM-bound passes, algorithmic bytes: BatchNorm forward = statistics (1 read) + apply (1 read,
+        # + the residual, 1 write); backward = two passes over dy, x (and y at residual sites) + 1 write
+        def bn(x, res, y, M, C, stats, prefix):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._bn(x, res, y, M, C, stats, prefix)
+            b.record()
+            self.hbm.append(("batchnorm+lrelu forward (statistics, apply)", M * C * es * (3 + (res is not None)), a, b))
+
+        def bn_bwd(dy, y, x, dx, M, C, stats, prefix):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._bn_bwd(dy, y, x, dx, M, C, stats, prefix)
+            b.record()
+            self.hbm.append(("batchnorm+lrelu backward (sums, dx)", M * C * es * (2 * (2 + (y is not None)) + 1), a, b))
+
+        eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd = fwd, wgrad, bn, bn_bwd
         return self
 
     def __exit__(self, *exc):
-        self.eng._fwd, self.eng._wgrad = self._fwd, self._wgrad
+        self.eng._fwd, self.eng._wgrad, self.eng._bn, self.eng._bn_bwd = self._fwd, self._wgrad, self._bn, self._bn_bwd
+
+    def timed(self, label, nbytes, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.hbm.append((label, nbytes, a, b))
+
+    def hbm_summary(self, reps):
+        torch.cuda.synchronize()
+        agg = {}
+        for label, nbytes, a, b in self.hbm:
+            s = agg.setdefault(label, [0.0, 0.0])
+            s[0] += nbytes
+            s[1] += a.elapsed_time(b) * 1e-3
+        return {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "frac_of_8TB/s": round(v[0] / v[1] / 8e12, 3),
+                    "ms_per_step": round(v[1] / reps * 1e3, 3)} for k, v in agg.items()}
 
     @staticmethod
     def kernel_name(g, kind):
@@ -321,7 +356,9 @@ def main():
             for _ in range(24):
                 torch.mm(wa, wa, out=wb)
             eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
+            kt.timed("adamw (28 B per parameter)", 28 * eng.arena_numel, lambda: eng.adamw_step(args.lr))
         agg = kt.summary()
+        hbm = kt.hbm_summary(2)
         if args.per_layer:
             print(kt.per_layer(2), file=sys.stderr)
     eng.overlap = overlap
@@ -342,7 +379,10 @@ def main():
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
                 "all_gemm_ms_per_step": round(total_gemm_t * 1e3, 3),
                 "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3)}
-                               for k, v in sorted(agg.items())}}
+                               for k, v in sorted(agg.items())},
+                # the step's HBM-bound passes: algorithmic bytes / event-bracketed time (small finalize
+                # kernels included), against the 8 TB/s HBM3E peak
+                "hbm_kernels": hbm}
 
     out = {
         "metric": "train images/sec", "value": round(B * world * args.steps / dt, 1), "unit": "images/sec",
