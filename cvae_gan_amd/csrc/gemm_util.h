@@ -48,6 +48,31 @@ __device__ __forceinline__ int wmap_index(const cvg_wmap& m, int n, int k) {
 }
 
 
+// wmap_index for R consecutive k of one row: the two integer divisions and the tap lookup are done
+// once when the run stays inside one tap (it almost always does: runs start at multiples of R and
+// the channel block kd is a multiple of 4 or 8), instead of once per element.
+template <int R>
+__device__ __forceinline__ void wmap_index_run(const cvg_wmap& m, int n, int k, int (&ci)[R]) {
+    const int j = k / m.kd, c = k - j * m.kd;
+    if (c + R > m.kd) {
+#pragma unroll
+        for (int e = 0; e < R; ++e) ci[e] = wmap_index(m, n, k + e);
+        return;
+    }
+    int t = j;
+    bool ok = n < m.n_valid && j < m.ntaps;
+    if (ok) {
+        if (m.tap_mode == 1) t = m.ntaps - 1 - j;
+        else if (m.tap_mode == 2) t = m.tap_table[j];
+        ok = t >= 0;
+    }
+    const int nq = n / m.nd, nr = n - nq * m.nd;
+    if (m.nr_valid > 0 && nr >= m.nr_valid) ok = false;
+    const int base = nq * m.na + nr * m.nb + t * m.ka;
+#pragma unroll
+    for (int e = 0; e < R; ++e) ci[e] = (ok && c + e < m.kc_valid) ? base + (c + e) * m.kb : -1;
+}
+
 // partial slabs [nsplit][n_rows][k_ld] -> canonical gradient (fixed summation order).  One thread
 // per 4 consecutive k (k_ld is a multiple of 4): 16-byte slab reads, four slabs in flight.
 static __global__ void __launch_bounds__(256) wgrad_reduce(const float* __restrict__ ws, float* __restrict__ grad,
@@ -59,8 +84,9 @@ static __global__ void __launch_bounds__(256) wgrad_reduce(const float* __restri
     const int n = (int)(idx / k4), k = (int)(idx % k4) * 4;
     int ci[4];
     bool any = false;
+    wmap_index_run<4>(map, n, k, ci);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ci[e] = wmap_index(map, n, k + e); any |= ci[e] >= 0; }
+    for (int e = 0; e < 4; ++e) any |= ci[e] >= 0;
     if (!any) return;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const size_t stride = (size_t)n_rows * k_ld;

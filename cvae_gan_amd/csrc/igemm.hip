@@ -431,24 +431,39 @@ template <typename T>
 __device__ __forceinline__ void pack_group(const cvg_pack_job& j, int64_t g) {
     int n, k;
     if (j.mode == 1) {                       // fragment order, see patch_pack
-        const int lane = (int)(g & 63);
-        const int64_t f = g >> 6;
-        const int nk = j.nchunks * j.ntaps * 2;
-        const int kstep = (int)(f % nk), nblk = (int)(f / nk);
-        n = nblk * 32 + (lane & 31);
-        const int chunk = kstep / (2 * j.ntaps), tap = (kstep >> 1) % j.ntaps, sub = kstep & 1;
-        k = tap * j.Cin + chunk * 32 + sub * 16 + 8 * (lane >> 5);
+        // Thread -> fragment piece with the tap varying fastest, then the row: canonical weights are
+        // [..][..][tap], so neighbouring threads read neighbouring floats (whole cache lines instead
+        // of one float per 32-byte sector); the 16-byte pieces they write interleave in L2.
+        const int T_ = j.ntaps;
+        int64_t u = g;
+        const int tap = (int)(u % T_); u /= T_;
+        const int nl = (int)(u & 31); u >>= 5;
+        const int hh = (int)(u & 1); u >>= 1;
+        const int sub = (int)(u & 1); u >>= 1;
+        const int chunk = (int)(u % j.nchunks);
+        const int nblk = (int)(u / j.nchunks);
+        const int kstep = (chunk * T_ + tap) * 2 + sub;
+        g = ((int64_t)nblk * (j.nchunks * T_ * 2) + kstep) * 64 + hh * 32 + nl;
+        n = nblk * 32 + nl;
+        k = tap * j.Cin + chunk * 32 + sub * 16 + 8 * hh;
     } else {
-        const int64_t idx = g * 8;
-        n = (int)(idx / j.ld);
-        k = (int)(idx % j.ld);
+        // row-major [n][tap * kd + c]: inside a row the threads walk the taps fastest for the same
+        // reason; the padding groups behind the last tap keep their places
+        const int G = j.ld >> 3, kd = j.map.kd, T_ = j.map.ntaps;
+        n = (int)(g / G);
+        const int u = (int)(g - (int64_t)n * G);
+        k = u * 8;
+        if ((kd & 7) == 0 && u < T_ * (kd >> 3)) {
+            const int cg = u / T_, tap = u - cg * T_;
+            k = tap * kd + cg * 8;
+            g = ((int64_t)n * j.ld + k) >> 3;
+        }
     }
     float v[8];
+    int ci[8];
+    wmap_index_run<8>(j.map, n, k, ci);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ci = wmap_index(j.map, n, k + e);
-        v[e] = ci >= 0 ? j.canonical[ci] : 0.f;
-    }
+    for (int e = 0; e < 8; ++e) v[e] = ci[e] >= 0 ? j.canonical[ci[e]] : 0.f;
     store8<T>((T*)j.packed + g * 8, v);
 }
 __global__ void __launch_bounds__(256) weight_pack_batch(const cvg_pack_job* __restrict__ jobs, int n_jobs) {
