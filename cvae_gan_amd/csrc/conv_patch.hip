@@ -84,7 +84,8 @@ patch_fwd(const PatchFwdArgs a) {
     constexpr int CPP = CK * ES / 16;            // 16-byte pieces per patch pixel
     constexpr int PITCH = CK * ES + 16;          // conflict-free ds_read_b128 across pixels
     constexpr int NT = 64 * WM * WN;             // 4 waves, or 2 (then four workgroups share a CU)
-    constexpr int NIT = NT == 256 ? 2 * CPP : 3 * CPP / 2;       // patch pieces per thread (patch_px <= 512 / 192)
+    constexpr int MAXPATCH = NT == 128 ? 192 : 512;                               // patch pixels a workgroup can stage
+    constexpr int NIT = (MAXPATCH * CPP + NT - 1) / NT;                           // patch pieces per thread
     constexpr int WTM = MI * 32, WTN = NI * 32, BN = WN * WTN;
     constexpr int FRAG = 64 * 8;                 // elements per packed fragment (one wave-load)
     // Taps unrolled per loop body = weight steps in flight per wave: all 9 taps of a 3x3 kernel,
@@ -95,8 +96,8 @@ patch_fwd(const PatchFwdArgs a) {
     // whose 8-pixel x 4-channel windows play the part of 32 "channels")
     constexpr int TU = KWT == 1 ? 7 : ((KWT == 3 && sizeof(T) == 2) ? 9 : KWT);   // f32 fragments are twice as wide: one tap row
     typedef typename Elem<T>::frag frag;
-    static_assert(NT == 256 || NT == 128, "4 or 2 waves");
-    static_assert(NIT * NT >= (NT == 256 ? 512 : 192) * CPP, "patch pieces");
+    static_assert(NT == 512 || NT == 256 || NT == 128, "8, 4 or 2 waves");
+    static_assert(NIT * NT >= MAXPATCH * CPP, "patch pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const TileGeom& t = a.t;
@@ -1041,7 +1042,14 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     int max_patch = 512;
     if (two_wave && d->dtype == CVG_BF16 && d->N > 32 && d->N <= 64) { p.BM = 128; max_patch = 192; }
     static const char* wide = getenv("CVG_PATCH_WIDE");            // experiment: 256 px x 128 ch tiles (bf16)
-    if (wide && wide[0] == '1' && d->N > 64 && d->dtype == CVG_BF16) p.BM = 256;
+    // Layers with two or more 128-channel output tiles run as ONE eight-wave workgroup per CU over 256
+    // pixels (wave tile unchanged: 32 ch x 128 px): each weight fragment is fetched from L2 once per
+    // 256 pixels and its second reader hits the L1, and each input patch is re-read by half as many
+    // workgroups.  Layer by layer -2..-25 % for N >= 256 and +5 % for N = 128 in isolation, but inside
+    // the step (weight-gradient stream running beside it) using it for every N > 64 is fastest.
+    // CVG_PATCH_WIDE: '0' never, '1' the four-wave form with 64 ch x 128 px wave tiles.
+    const char mode = wide ? wide[0] : 'a';
+    if (d->dtype == CVG_BF16 && d->N > 64 && mode != '0') p.BM = 256;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
     p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
@@ -1076,7 +1084,9 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
     a.lane_perm = (p.TW % 16 == 0) ? 1 : 0;
     {   // pixels per thread in the store phase: BM * (BN * es / 16) / threads
-        const int threads = (p.BN == 64 && p.BM == 128) ? 128 : 256;
+        static const char* wide8 = getenv("CVG_PATCH_WIDE");
+        const bool four = wide8 && wide8[0] == '1';
+        const int threads = (p.BN == 64 && p.BM == 128) ? 128 : ((p.BN == 128 && p.BM == 256 && !four) ? 512 : 256);
         const int pt = p.BM * (p.BN * es / 16) / threads;
         a.row_fast = (p.TW % pt == 0) ? 1 : 0;
     }
@@ -1092,7 +1102,11 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
     if (d->dtype == CVG_BF16) {
-        if (p.BN == 128 && p.BM == 256) return launch_patch_fwd<bf16, 2, 2, 4, 2>(p, a, s);
+        if (p.BN == 128 && p.BM == 256) {
+            static const char* w8 = getenv("CVG_PATCH_WIDE");
+            if (w8 && w8[0] == '1') return launch_patch_fwd<bf16, 2, 2, 4, 2>(p, a, s);
+            return launch_patch_fwd<bf16, 2, 4, 4, 1>(p, a, s);       // eight waves, 32 ch x 128 px each
+        }
         if (p.BN == 128) return launch_patch_fwd<bf16, 1, 4, 4, 1>(p, a, s);
         if (p.BN == 64 && p.BM == 128) return launch_patch_fwd<bf16, 1, 2, 4, 1>(p, a, s);
         if (p.BN == 64) return launch_patch_fwd<bf16, 2, 2, 4, 1>(p, a, s);

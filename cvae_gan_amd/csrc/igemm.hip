@@ -708,7 +708,10 @@ const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {
     if (patch_enabled()) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
-        if (pp.ok) return pp.BN == 128 ? "patch_fwd<128px x 128ch>" : (pp.BN == 64 ? "patch_fwd<256px x 64ch>" : "patch_fwd<256px x 32ch>");
+        if (pp.ok) {
+            if (pp.BN == 128) return pp.BM == 256 ? "patch_fwd<256px x 128ch>" : "patch_fwd<128px x 128ch>";
+            return pp.BN == 64 ? "patch_fwd<256px x 64ch>" : "patch_fwd<256px x 32ch>";
+        }
     }
     return d->N > 64 ? "igemm_fwd<128x128>" : (d->N > 32 ? "igemm_fwd<256x64>" : "igemm_fwd<256x32>");
 }

@@ -23,7 +23,7 @@ def family(name):
             wn = nums[0]
             wm = 4 // wn if wn else None
         if wn == 4:
-            return "patch_fwd<128px x 128ch>"
+            return "patch_fwd<256px x 128ch>" if wm == 2 else "patch_fwd<128px x 128ch>"
         if wn == 2:
             return "patch_fwd<256px x 64ch>"
         if wn == 1:
