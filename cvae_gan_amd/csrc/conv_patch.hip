@@ -1251,7 +1251,8 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     }
     if (rc) return rc;
     const int64_t n = (int64_t)map->n_valid * (a.k_ld / 4);
-    wgrad_reduce<<<ceil_div(n, 256), 256, 0, s>>>(ws, grad, *map, a.n_rows, a.k_ld, p.nsplit, accumulate);
+    const int zg = wgrad_reduce_zg(n, p.nsplit);
+    wgrad_reduce<<<ceil_div(n, 256 / zg), 256, 0, s>>>(ws, grad, *map, a.n_rows, a.k_ld, p.nsplit, accumulate, zg);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -74,39 +74,65 @@ __device__ __forceinline__ void wmap_index_run(const cvg_wmap& m, int n, int k, 
 }
 
 // partial slabs [nsplit][n_rows][k_ld] -> canonical gradient (fixed summation order).  One thread
-// per 4 consecutive k (k_ld is a multiple of 4): 16-byte slab reads, four slabs in flight.
+// per 4 consecutive k (k_ld is a multiple of 4) and slab range: 16-byte slab reads, four slabs in
+// flight.  zg (1, 2, 4 or 8, chosen by the launcher) slab ranges per output share a workgroup and
+// meet in LDS in range order: small layers (a 64 -> 64 conv has 9216 such outputs) otherwise leave
+// most CUs idle while a few dozen workgroups walk hundreds of slabs each.
 static __global__ void __launch_bounds__(256) wgrad_reduce(const float* __restrict__ ws, float* __restrict__ grad,
                                                            const cvg_wmap map, int n_rows, int k_ld, int nsplit,
-                                                           int accumulate) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                           int accumulate, int zg) {
+    __shared__ f32x4 part[256];
+    const int lo_n = 256 / zg, lo = threadIdx.x % lo_n, zi = threadIdx.x / lo_n;
+    const int64_t idx = (int64_t)blockIdx.x * lo_n + lo;
     const int k4 = k_ld >> 2;
-    if (idx >= (int64_t)map.n_valid * k4) return;
-    const int n = (int)(idx / k4), k = (int)(idx % k4) * 4;
-    int ci[4];
+    const bool live = idx < (int64_t)map.n_valid * k4;
+    const int n = live ? (int)(idx / k4) : 0, k = live ? (int)(idx % k4) * 4 : 0;
+    int ci[4] = {-1, -1, -1, -1};
     bool any = false;
-    wmap_index_run<4>(map, n, k, ci);
+    if (live) {
+        wmap_index_run<4>(map, n, k, ci);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) any |= ci[e] >= 0;
-    if (!any) return;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    const size_t stride = (size_t)n_rows * k_ld;
-    const float* p = ws + (size_t)n * k_ld + k;
-    int z = 0;
-    for (; z + 4 <= nsplit; z += 4) {
-        f32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p + (size_t)(z + u) * stride);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+        for (int e = 0; e < 4; ++e) any |= ci[e] >= 0;
     }
-    for (; z < nsplit; ++z) {
-        const f32x4 v = *(const f32x4*)(p + (size_t)z * stride);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (any) {
+        const size_t stride = (size_t)n_rows * k_ld;
+        const float* p = ws + (size_t)n * k_ld + k;
+        const int per = (nsplit + zg - 1) / zg;
+        int z = zi * per;
+        const int z_end = min(nsplit, z + per);
+        for (; z + 4 <= z_end; z += 4) {
+            f32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += v[e];
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p + (size_t)(z + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+        }
+        for (; z < z_end; ++z) {
+            const f32x4 v = *(const f32x4*)(p + (size_t)z * stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
+    }
+    if (zg > 1) {
+        part[threadIdx.x] = f32x4{s[0], s[1], s[2], s[3]};
+        __syncthreads();
+        if (zi != 0) return;
+        for (int q = 1; q < zg; ++q) {
+            const f32x4 v = part[q * lo_n + lo];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (ci[e] >= 0) grad[ci[e]] = accumulate ? grad[ci[e]] + s[e] : s[e];
+}
+// slab ranges per output for wgrad_reduce: enough threads for the whole GPU, at least 4 slabs per range
+static inline int wgrad_reduce_zg(int64_t outputs4, int nsplit) {
+    int zg = 1;
+    while (zg < 8 && outputs4 * zg < 131072 && nsplit >= 8 * zg) zg *= 2;
+    return zg;
 }

@@ -760,7 +760,8 @@ int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_
     int rc = d->dtype == CVG_BF16 ? launch_wgrad<bf16>(p, a, s) : launch_wgrad<float>(p, a, s);
     if (rc) return rc;
     const int64_t n = (int64_t)map->n_valid * (p.k_ld / 4);
-    wgrad_reduce<<<ceil_div(n, 256), 256, 0, s>>>(a.ws, grad, *map, p.n_rows, p.k_ld, p.nsplit, accumulate);
+    const int zg = wgrad_reduce_zg(n, p.nsplit);
+    wgrad_reduce<<<ceil_div(n, 256 / zg), 256, 0, s>>>(a.ws, grad, *map, p.n_rows, p.k_ld, p.nsplit, accumulate, zg);
     CVG_LAUNCH_CHECK();
     return 0;
 }
