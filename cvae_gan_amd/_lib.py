@@ -65,6 +65,8 @@ def _load():
         "cvg_bn_stats": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
         "cvg_bn_act_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
         "cvg_bn_eval_stats": (C.c_int, [vp, vp, i32, vp, vp]),
+        "cvg_bn_eval_scale_shift": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp]),
+        "cvg_conv_bn_act_fwd": (C.c_int, [P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "cvg_bn_act_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "cvg_colsum": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
         "cvg_permute_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

@@ -19,7 +19,8 @@ struct PatchPlan {
 void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p);
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
-                     const void* gate, hipStream_t s);
+                     const void* gate, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr,
+                     int act = 0);
 // Weights in MFMA-fragment order: [n/32][chunk][tap][k16 half][lane][8].
 int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap* map, const float* canonical,
                       void* packed, hipStream_t s);

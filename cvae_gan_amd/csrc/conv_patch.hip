@@ -28,6 +28,7 @@ struct TileGeom {
 struct PatchFwdArgs {
     const void* x; const void* wf; void* y;
     const float* bias; const float* cbias; const int* labels; const void* res; const void* gate;
+    const float* scale; const float* shift; int act;     // eval-mode BatchNorm + LeakyReLU in the epilogue
     int B, H, W, Cin, x_img_pitch, x_row_pitch, x_pix_pitch;
     int off_y, off_x, pad_mode, KW, T;
     int OH, OW, N;
@@ -202,7 +203,7 @@ patch_fwd(const PatchFwdArgs a) {
     // A residual term (res * LeakyReLU'(gate), the skip branch of a res block's input gradient)
     // starts the accumulators: its scattered 8-byte reads are in flight while the first patch and
     // the weight ring fill, instead of sitting in the epilogue.
-    if (a.res) {
+    if (a.res && !a.scale) {
         const T* __restrict__ resp = (const T*)a.res;
         const T* __restrict__ gatep = (const T*)a.gate;
 #pragma unroll
@@ -317,11 +318,15 @@ patch_fwd(const PatchFwdArgs a) {
     for (int mi = 0; mi < MI; ++mi) {
         const int ql = wm * WTM + mi * 32 + lpx;
         const float* cb = nullptr;
-        if (per_pixel) {
+        const T* rs = nullptr;                   // residual row of this pixel (scaled-epilogue mode only)
+        if (per_pixel || (a.scale && a.res)) {
             int tb, ty, tx;
             tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
-            const int b = b0 + tb;
-            if (ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
+            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            if (per_pixel && ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
+            if (a.scale && a.res && ql < t.npx && b < a.B && oy < a.OH && ox < a.OW)
+                rs = (const T*)a.res + (b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
+                                        (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch);
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -339,6 +344,20 @@ patch_fwd(const PatchFwdArgs a) {
                     if (cb) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
+                    }
+                    if (a.scale) {               // y = act(scale * conv + shift + res)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] * a.scale[n + j] + a.shift[n + j];
+                        if (rs) {
+                            float r[4];
+                            load4<T>(rs + n, r);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += r[j];
+                        }
+                        if (a.act) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : LRELU_SLOPE * v[j];
+                        }
                     }
                 }
                 store4<T>((T*)(smem + ql * OP) + nl, v);
@@ -1069,8 +1088,9 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
 
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
-                     const void* gate, hipStream_t s) {
+                     const void* gate, hipStream_t s, const float* scale, const float* shift, int act) {
     PatchFwdArgs a;
+    a.scale = scale; a.shift = shift; a.act = act;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels; a.res = res; a.gate = gate;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch; a.x_pix_pitch = d->x_pix_pitch;

@@ -378,6 +378,17 @@ __global__ void axpy_f32(float* __restrict__ y, const float* __restrict__ x, flo
     if (i < n) y[i] += alpha * x[i];
 }
 
+// eval-mode BatchNorm as one multiply-add per channel: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+__global__ void bn_eval_scale_shift(const float* __restrict__ rm, const float* __restrict__ rv,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                    float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * (1.f / sqrtf(rv[c] + BN_EPS));
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
 // ---- small vector helpers -----------------------------------------------------------------
 __global__ void permute_f32(const float* in, float* out, int n, int d, int a, int b) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -981,6 +992,13 @@ int cvg_bn_eval_stats(const float* rm, const float* rv, int32_t C, float* stats,
     return 0;
 }
 
+int cvg_bn_eval_scale_shift(const float* rm, const float* rv, const float* gamma, const float* beta, int32_t C,
+                            float* scale, float* shift, cvg_stream stream) {
+    CVG_CHECK(rm && rv && gamma && beta && scale && shift && C > 0, "bn_eval_scale_shift: bad args");
+    bn_eval_scale_shift<<<grid1(C), 256, 0, (hipStream_t)stream>>>(rm, rv, gamma, beta, C, scale, shift);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
 int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32_t M, int32_t C, const float* stats,
                    const float* gamma, const float* beta, cvg_stream stream) {
     if (check_rows("bn_act_fwd", M, C)) return -1;

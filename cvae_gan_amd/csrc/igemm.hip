@@ -654,6 +654,19 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     return d->dtype == CVG_BF16 ? launch_fwd<bf16>(d, a, s) : launch_fwd<float>(d, a, s);
 }
 
+int cvg_conv_bn_act_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                        const float* cbias, const int32_t* labels, const float* scale, const float* shift,
+                        const void* res, cvg_stream stream) {
+    CVG_CHECK(d && x && w && y && scale && shift, "conv_bn_act_fwd: null argument");
+    CVG_CHECK(!cbias || labels, "conv_bn_act_fwd: cbias needs labels");
+    CVG_CHECK(d->N > 0 && d->N % 4 == 0, "conv_bn_act_fwd: N %d must be a multiple of 4", d->N);
+    PatchPlan pp;
+    pp.ok = 0;
+    if (patch_enabled()) patch_fwd_plan(d, pp);
+    CVG_CHECK(pp.ok, "conv_bn_act_fwd: this layer runs on the gather kernel; use cvg_conv_fwd + cvg_bn_act_fwd");
+    return patch_fwd_launch(d, pp, x, w, y, bias, cbias, labels, res, nullptr, (hipStream_t)stream, scale, shift, 1);
+}
+
 int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x, const void* const* w, void* y,
                        cvg_stream stream) {
     CVG_CHECK(n >= 1 && n <= 4 && descs && x && w && y, "conv_fwd_group: bad args");

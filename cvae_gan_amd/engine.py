@@ -574,6 +574,19 @@ class Engine:
             ops.bn_eval_stats(self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"], C, stats)
         ops.bn_act_fwd(x, res, y, M, C, stats, self.params[prefix + ".weight"], self.params[prefix + ".bias"])
 
+    def _conv_bn(self, g, x, conv_out, res, y, M, C, stats, prefix, bias=None, **kw):
+        """conv -> BatchNorm(+res) -> LeakyReLU.  Training: the convolution, then batch statistics and
+        the apply pass.  Inference: running statistics fold into one multiply-add per channel, applied
+        in the convolution's epilogue (no normalisation pass, conv_out is not written)."""
+        if not self.training and ops.conv_fwd_kernel(g.desc).startswith("patch_fwd"):
+            sc, sh = self._bn_scratch[0][:C], self._bn_scratch[1][:C]
+            ops.bn_eval_scale_shift(self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"],
+                                    self.params[prefix + ".weight"], self.params[prefix + ".bias"], C, sc, sh)
+            ops.conv_bn_act_fwd(g.desc, x, g.w, y, sc, sh, bias=bias, res=res, **kw)
+            return
+        self._fwd(g, x, conv_out, bias=bias, **kw)
+        self._bn(conv_out, res, y, M, C, stats, prefix)
+
     def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix):
         """y=None for a BatchNorm without a residual input: the gate is recomputed from x."""
         if self._frozen:        # parameters are constants in this pass: dgamma / dbeta only serve dx
@@ -629,16 +642,14 @@ class Engine:
         if self.y > 0:
             e["labels"].copy_(labels)
         ops.pack_image(x, e["xpad"], B, P)
-        self._fwd(e["stem"], e["xpad"], e["s0"], bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],
-                  labels=e["labels"] if self.y > 0 else None)
-        self._bn(e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2")
+        self._conv_bn(e["stem"], e["xpad"], e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2",
+                      bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],
+                      labels=e["labels"] if self.y > 0 else None)
         xin = e["a0"]
         for blk in e["blocks"]:
             p, M, C = blk["prefix"], blk["M"], blk["cin"]
-            self._fwd(blk["conv1"], xin, blk["c1"])
-            self._bn(blk["c1"], None, blk["b1"], M, C, blk["st1"], p + "res.res.1")
-            self._fwd(blk["conv2"], blk["b1"], blk["c2"])
-            self._bn(blk["c2"], xin, blk["r"], M, C, blk["st2"], p + "res.res.4")
+            self._conv_bn(blk["conv1"], xin, blk["c1"], None, blk["b1"], M, C, blk["st1"], p + "res.res.1")
+            self._conv_bn(blk["conv2"], blk["b1"], blk["c2"], xin, blk["r"], M, C, blk["st2"], p + "res.res.4")
             self._fwd(blk["down"], blk["r"], blk["out"])
             blk["xin"] = xin
             xin = blk["out"]

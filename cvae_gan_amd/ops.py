@@ -252,3 +252,13 @@ def axpy(y, x, alpha, n=None):
     """y += alpha * x (f32)."""
     assert y.dtype == torch.float32 and x.dtype == torch.float32
     check(lib.cvg_axpy_f32(ptr(y), ptr(x), alpha, y.numel() if n is None else n, stream()))
+
+
+# ---- inference: eval-mode BatchNorm + LeakyReLU in the convolution's epilogue ----------------
+def bn_eval_scale_shift(rm, rv, gamma, beta, C_, scale, shift):
+    check(lib.cvg_bn_eval_scale_shift(ptr(rm), ptr(rv), ptr(gamma), ptr(beta), C_, ptr(scale), ptr(shift), stream()))
+
+
+def conv_bn_act_fwd(desc, x, w, y, scale, shift, bias=None, cbias=None, labels=None, res=None):
+    check(lib.cvg_conv_bn_act_fwd(C.byref(desc), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(cbias), ptr(labels),
+                                  ptr(scale), ptr(shift), ptr(res), stream()))

@@ -185,6 +185,19 @@ int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32
                    const float* stats, const float* gamma, const float* beta, cvg_stream s);
 int cvg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C,
                       float* stats, cvg_stream s);
+/* Inference (module.eval(), models/cvae.py:167 and :209): BatchNorm with running statistics is one
+ * multiply-add per channel, scale = gamma / sqrt(running_var + eps), shift = beta - running_mean *
+ * scale, and is applied in the epilogue of the convolution in front of it:
+ *   y = LeakyReLU_0.2( (conv(x, w) + bias + cbias[label]) * scale[n] + shift[n] + res )
+ * (res: the res block's skip tensor, addressed like y, or NULL), replacing nn.Conv2d +
+ * nn.BatchNorm2d + nn.LeakyReLU at models/networks.py:173-175 and :233-243 without the separate
+ * normalisation pass.  Only for layers the patch kernel takes (cvg_conv_fwd_kernel() names
+ * "patch_fwd..."); others keep cvg_conv_fwd + cvg_bn_eval_stats + cvg_bn_act_fwd.               */
+int cvg_bn_eval_scale_shift(const float* running_mean, const float* running_var, const float* gamma,
+                            const float* beta, int32_t C, float* scale, float* shift, cvg_stream s);
+int cvg_conv_bn_act_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y,
+                        const float* bias, const float* cbias, const int32_t* labels,
+                        const float* scale, const float* shift, const void* res, cvg_stream s);
 /* Backward of the same: g = dy * (y > 0 ? 1 : 0.2);
  * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
  * The residual branch's gradient is g itself; consumers recompute it from (dy, y)

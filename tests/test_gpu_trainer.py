@@ -100,3 +100,37 @@ def test_device_prefetcher_matches_host_pipeline(tmp_path):
         ref = ((u8.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
         assert torch.allclose(x.cpu(), ref, atol=1e-6)
         assert l.cpu().tolist() == [(8 * k + i) % 5 for i in range(8)]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_eval_conv_epilogue_batchnorm_equals_separate_pass(dtype, tol, monkeypatch):
+    """Inference folds running-statistics BatchNorm + LeakyReLU (+ the skip tensor) into the
+    convolution's epilogue (cvg_conv_bn_act_fwd).  Same network, same inputs, with the separate
+    normalisation pass forced instead: f32 results agree to rounding, bf16 to one rounding of the
+    intermediate the fused form no longer stores."""
+    from cvae_gan_amd import ops
+    from cvae_gan_amd.engine import Engine
+    P, y, z, B = 32, 10, 32, 16
+    eng = Engine(P, y, z, B, dtype=dtype, seed=9)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for k, buf in eng.buffers.items():          # non-trivial running statistics
+        if k.endswith("running_mean"):
+            buf.copy_(torch.randn(buf.shape, device="cuda", generator=g) * 0.1)
+        elif k.endswith("running_var"):
+            buf.copy_(torch.rand(buf.shape, device="cuda", generator=g) + 0.5)
+    x = torch.rand(B, 3, P, P, device="cuda", generator=g) * 2 - 1
+    labels = torch.randint(0, y, (B,), device="cuda", generator=g, dtype=torch.int32)
+    eps = torch.randn(B, z, device="cuda", generator=g)
+    eng.training = False
+    assert ops.conv_fwd_kernel(eng.enc["blocks"][0]["conv1"].desc).startswith("patch_fwd")
+    fused = eng.reconstruct(x, labels, eps).clone()
+    h_fused = eng.enc["h"].float().clone()
+    monkeypatch.setattr(ops, "conv_fwd_kernel", lambda desc: "separate")
+    plain = eng.reconstruct(x, labels, eps).clone()
+    h_plain = eng.enc["h"].float().clone()
+    torch.cuda.synchronize()
+    assert float((h_fused - h_plain).abs().max()) <= tol * max(float(h_plain.abs().max()), 1.0)
+    # the decoder holds no BatchNorm; at a random initialisation its tanh is saturated, so the images
+    # are compared in f32 only (in bf16 a 1e-2 change of h flips saturated pixels)
+    if dtype == torch.float32:
+        assert float((fused - plain).abs().max()) <= 1e-3
