@@ -225,14 +225,18 @@ def main():
     batch_size_flag = float(B * world)       # the reference divides both losses by --batch_size (global)
     loss_scale = 1.0 / world
 
-    # N > 1: the gradient arena is exchanged in two ranges (it is laid out in the order backward
-    # finishes gradients: the decoder's first), each as one SUM all-reduce on a side stream.  The
-    # decoder's range travels while the encoder's backward pass runs.
+    # N > 1: the gradient arena is exchanged in three ranges (it is laid out in the order backward
+    # finishes gradients), each as one SUM all-reduce on a side stream: the decoder's (33 MB at c3)
+    # travels while the encoder's head and deep blocks run backward, theirs (45 MB: nearly all of the
+    # encoder's parameters) while the shallow blocks and the stem run, which are the longest part of
+    # the encoder's backward pass; only the last range (1.5 MB) is exposed.
     force_ddp = os.environ.get("CVG_BENCH_FORCE_DDP") is not None      # rehearse the N > 1 control flow on one rank
     multi = world > 1 or force_ddp
     ranges = ddp.stage_ranges(eng.arena_order, eng.arena_offsets, eng.arena_numel)
     dec_lo, dec_hi = ranges["dec"]
     assert dec_lo == 0, "the decoder's gradients lead the arena"
+    up_lo, up_hi = eng.enc_upper_range()
+    assert up_lo == dec_hi, "the encoder's head follows the decoder in the arena"
     comm = torch.cuda.Stream() if multi else None
 
     def exchange(lo, hi):
@@ -254,8 +258,10 @@ def main():
         if multi:
             eng.forward_backward_decoder(x, labels, eps, batch_size_flag, loss_scale)
             exchange(dec_lo, dec_hi)
-            eng.enc_backward(eng.enc["dh"])
-            exchange(dec_hi, eng.arena_numel)
+            eng.enc_backward(eng.enc["dh"], part="upper")
+            exchange(up_lo, up_hi)
+            eng.enc_backward(eng.enc["dh"], part="lower")
+            exchange(up_hi, eng.arena_numel)
             torch.cuda.current_stream().wait_stream(comm)
         else:
             eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
@@ -263,9 +269,10 @@ def main():
         eng.adamw_step(args.lr)
 
     # A HIP graph of one whole step removes the per-launch host cost (about 200 launches per step).
-    # With N > 1 the step is three graphs with the gradient exchange between them: [forward +
-    # decoder backward] -> all-reduce of the decoder's gradient range (on a side stream, overlapping
-    # the next graph) -> [encoder backward] -> all-reduce of the encoder's range -> [AdamW].
+    # With N > 1 the step is four graphs with the gradient exchanges between them: [forward +
+    # decoder backward] -> all-reduce of the decoder's range (on a side stream, overlapping the next
+    # graph) -> [encoder head + deep blocks backward] -> all-reduce of their range -> [shallow blocks
+    # + stem backward] -> all-reduce of the rest -> [AdamW].
     use_graph = not args.no_graph
     for i in range(max(args.warmup, 1)):
         step(i)
@@ -288,14 +295,16 @@ def main():
             def run_graphs():
                 graph.replay()
         else:
-            g_head, g_enc, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g_head, g_enc, g_enc2, g_opt = (torch.cuda.CUDAGraph() for _ in range(4))
             pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(g_head, pool=pool):
                 eng.random_mask()
                 eng._packed_version = -1
                 eng.forward_backward_decoder(gx, gl, ge, batch_size_flag, loss_scale)
             with torch.cuda.graph(g_enc, pool=pool):
-                eng.enc_backward(eng.enc["dh"])
+                eng.enc_backward(eng.enc["dh"], part="upper")
+            with torch.cuda.graph(g_enc2, pool=pool):
+                eng.enc_backward(eng.enc["dh"], part="lower")
             with torch.cuda.graph(g_opt, pool=pool):
                 eng.adamw_step(args.lr)
 
@@ -303,7 +312,9 @@ def main():
                 g_head.replay()
                 exchange(dec_lo, dec_hi)
                 g_enc.replay()
-                exchange(dec_hi, eng.arena_numel)
+                exchange(up_lo, up_hi)
+                g_enc2.replay()
+                exchange(up_hi, eng.arena_numel)
                 torch.cuda.current_stream().wait_stream(comm)
                 g_opt.replay()
         eng.step_count = saved

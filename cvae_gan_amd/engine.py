@@ -658,18 +658,47 @@ class Engine:
         self._fwd(e["fc3"], e["f1"], e["h"], bias=self.params[EP + "fc.3.bias"])
         return e["h"]
 
-    def enc_backward(self, dh, param_grads=True, input_grad=False):
+    def enc_backward(self, dh, param_grads=True, input_grad=False, part=None):
         """param_grads=False: the parameters are constants in this pass (a critic judging the
         generator): no weight / bias gradients are produced and self.grads is left alone.
-        input_grad=True (needs stem_input_grad at construction): also returns dL/dx as f32 NCHW."""
+        input_grad=True (needs stem_input_grad at construction): also returns dL/dx as f32 NCHW.
+        part: None = the whole pass; "upper" = the head and the deep blocks (index >= enc_split),
+        which hold nearly all of the encoder's parameters; "lower" = the remaining blocks and the
+        stem.  A data-parallel driver exchanges the upper gradients while "lower" runs."""
         self._frozen = not param_grads
         try:
-            return self._enc_backward(dh, input_grad)
+            return self._enc_backward(dh, input_grad, part)
         finally:
             self._frozen = False
 
-    def _enc_backward(self, dh, input_grad):
+    @property
+    def enc_split(self):
+        return len(self.enc["blocks"]) // 2
+
+    def enc_upper_range(self):
+        """[lo, hi) of the gradient arena written by enc_backward(part="upper")."""
+        lo = min(self.arena_offsets[k] for k in self.arena_order if k.startswith(EP + "fc."))
+        first_lower = EP + "conv.%d." % (4 + self.enc_split - 1)
+        hi = min(self.arena_offsets[k] for k in self.arena_order if k.startswith(first_lower))
+        return lo, hi
+
+    def _enc_backward(self, dh, input_grad, part=None):
         e, B, P, ngf = self.enc, self.B, self.P, self.ngf
+        frozen = self._frozen
+        last = e["blocks"][-1]
+        if part != "lower":
+            self._enc_backward_head(dh)
+        hi = len(e["blocks"]) - 1 if part != "lower" else self.enc_split - 1
+        lo = 0 if part != "upper" else self.enc_split
+        for i in range(hi, lo - 1, -1):
+            self._enc_backward_block(i)
+        if part == "upper":
+            self._join()
+            return None
+        return self._enc_backward_stem(input_grad)
+
+    def _enc_backward_head(self, dh):
+        e, B = self.enc, self.B
         frozen = self._frozen
         last = e["blocks"][-1]
         with self._branch():
@@ -684,23 +713,29 @@ class Engine:
                 ops.colsum(e["d_f0"], B, e["fcd"], e["fcd"], self.grads[EP + "fc.0.bias"], self.red_ws_side)
         self._fwd(e["fc0_dg"], e["d_f0"], last["d_out"])
         self._ready("enc.head")
-        for i in range(len(e["blocks"]) - 1, -1, -1):
-            blk = e["blocks"][i]
-            p, M, C = blk["prefix"], blk["M"], blk["cin"]
-            with self._branch():
-                self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
-            blk["dgd_group"].run(blk["d_out"], blk["d_r"])
-            self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
-            with self._branch():
-                self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
-            self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"])
-            self._bn_bwd(blk["d_b1"], None, blk["c1"], blk["d_c1"], M, C, blk["st1"], p + "res.res.1")
-            with self._branch():
-                self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
-            d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
-            # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
-            self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
-            self._ready("enc.blk%d" % i)
+
+    def _enc_backward_block(self, i):
+        e = self.enc
+        blk = e["blocks"][i]
+        p, M, C = blk["prefix"], blk["M"], blk["cin"]
+        with self._branch():
+            self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
+        blk["dgd_group"].run(blk["d_out"], blk["d_r"])
+        self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
+        with self._branch():
+            self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
+        self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"])
+        self._bn_bwd(blk["d_b1"], None, blk["c1"], blk["d_c1"], M, C, blk["st1"], p + "res.res.1")
+        with self._branch():
+            self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
+        d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
+        # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
+        self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
+        self._ready("enc.blk%d" % i)
+
+    def _enc_backward_stem(self, input_grad):
+        e, B, P, ngf = self.enc, self.B, self.P, self.ngf
+        frozen = self._frozen
         self._bn_bwd(e["d_a0"], None, e["s0"], e["d_s0"], B * P * P, ngf, e["st0"], EP + "conv.2")
         with self._branch():
             self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)

@@ -81,3 +81,30 @@ def test_c3_full_batch_bf16_is_deterministic_and_linear():
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
     assert torch.equal(runs[2][1], runs[0][1])                 # the reported losses are unscaled
     assert torch.equal(runs[2][0], 2.0 * runs[0][0])
+
+
+def test_split_encoder_backward_equals_whole():
+    """enc_backward(part="upper") + enc_backward(part="lower") (the data-parallel schedule) writes the
+    same gradients, bit for bit, as the single pass, and the upper part touches exactly the arena
+    range enc_upper_range() names."""
+    from cvae_gan_amd.engine import Engine
+    B = 16
+    x, labels, eps, mask = _inputs(B, 6)
+    x, labels, eps = x.cuda(), labels.int().cuda(), eps.cuda()
+    eng = Engine(P, Y, Z, B, dtype=torch.bfloat16, seed=3)
+    eng.set_mask(mask)
+    eng.forward_backward(x, labels, eps, float(B))
+    torch.cuda.synchronize()
+    whole = eng.g_arena.clone()
+    eng.forward_backward_decoder(x, labels, eps, float(B))
+    lo, hi = eng.enc_upper_range()
+    eng.g_arena[lo:].fill_(float("nan"))
+    eng.enc_backward(eng.enc["dh"], part="upper")
+    torch.cuda.synchronize()
+    assert torch.equal(eng.g_arena[lo:hi], whole[lo:hi])
+    assert torch.isnan(eng.g_arena[hi:]).all()          # (arena padding included: nothing below was written)
+    eng.enc_backward(eng.enc["dh"], part="lower")
+    torch.cuda.synchronize()
+    pad = torch.isnan(eng.g_arena)                      # alignment gaps between tensors stay untouched
+    assert torch.equal(eng.g_arena[~pad], whole[~pad])
+    assert int(pad.sum()) < 64
