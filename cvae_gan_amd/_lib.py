@@ -5,6 +5,12 @@ fails loudly; there is no CPU or PyTorch fallback."""
 import ctypes as C
 import os
 
+# torch first: it brings the HIP runtime its streams and allocations live in, and the library must
+# bind to that same copy.  Loaded the other way round (this library first, e.g. `python -m
+# cvae_gan_amd.starter`), the process ends up with two runtimes and every launch on a torch stream
+# fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVG_LIB") or os.path.join(_HERE, "lib", "libcvaegan_hip.so")   # CVG_LIB: A/B builds
 

@@ -39,12 +39,17 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    os.environ.setdefault("CUDA_VISIBLE_DEVICES", args.gpus.split(",")[0])   # one process drives one GPU
     import torch
     from .cvae import CVAE
     if not torch.cuda.is_available():
         raise SystemExit("cvae_gan_amd needs an MI355X: no GPU is visible")
-    args.device = torch.device("cuda")
+    # one process drives one GPU: the first index of --gpus, if it is visible.  (The visibility
+    # variables are left alone: the HIP runtime is already loaded by the time the flags are parsed,
+    # and changing them afterwards leaves it without a device.)
+    first = int(args.gpus.split(",")[0] or 0)
+    if 0 <= first < torch.cuda.device_count():
+        torch.cuda.set_device(first)
+    args.device = torch.device("cuda", torch.cuda.current_device())
     os.makedirs(args.result_dir, exist_ok=True)
     os.makedirs(args.save_dir, exist_ok=True)
     model = CVAE(args)

@@ -134,3 +134,20 @@ def test_eval_conv_epilogue_batchnorm_equals_separate_pass(dtype, tol, monkeypat
     # are compared in f32 only (in bf16 a 1e-2 change of h flips saturated pixels)
     if dtype == torch.float32:
         assert float((fused - plain).abs().max()) <= 1e-3
+
+
+def test_starter_command_line(tmp_path):
+    """`python -m cvae_gan_amd.starter` with the reference's flags in a fresh process (the package is
+    imported before torch there: the library must still bind to torch's HIP runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "cvae_gan_amd.starter", "--dataset", "Synth", "--data_dir", str(tmp_path / "none"),
+           "--data_size", "64", "--pix_dim", "32", "--y_dim", "4", "--z_dim", "8", "--batch_size", "16", "--epoch", "1",
+           "--max_iters", "3", "--lrG", "1e-3", "--worker", "0", "--gpus", "0",
+           "--save_dir", str(tmp_path / "ck"), "--result_dir", str(tmp_path / "res")]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Training finish" in r.stdout
+    d = os.path.join(str(tmp_path / "ck"), "VAE_data_Synth_pix_32_batch_16_embed_8")
+    assert os.path.exists(os.path.join(d, "Synth_encoder.pkl")) and os.path.exists(os.path.join(d, "Synth_decoder.pkl"))
