@@ -48,10 +48,17 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
         }
     }
     if (rl < RL) {
-        for (int64_t m = (int64_t)blockIdx.x * RL + rl; m < a.M; m += (int64_t)gridDim.x * RL) {
+        // two rows per trip: their loads are issued together (twice the bytes in flight per thread),
+        // the sums are taken in row order, so the result does not depend on the pairing
+        const int NQ = (MODE == RED_BNBWD) ? 3 : (MODE == RED_BNBWD_X ? 2 : 1);
+        const int64_t stride = (int64_t)gridDim.x * RL;
+        auto fetch = [&](int64_t m, float (&v)[8], float (&d)[8], float (&o)[8]) {
             const size_t off = (size_t)m * a.ld + c_off + chunk * 8;
-            float v[8];
             load8<T>((const T*)a.x + off, v);
+            if (NQ >= 2) load8<T>((const T*)a.dy + off, d);
+            if (NQ >= 3) load8<T>((const T*)a.y + off, o);
+        };
+        auto add = [&](float (&v)[8], float (&d)[8], float (&o)[8]) {
             if (MODE == RED_STATS) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * v[j]; }
@@ -59,13 +66,9 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s0[j] += v[j];
             } else {
-                float d[8], o[8];
-                load8<T>((const T*)a.dy + off, d);
                 if (from_x) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = v[j] * sc[j] + sh[j];
-                } else {
-                    load8<T>((const T*)a.y + off, o);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -74,6 +77,18 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
                     s1[j] += g * (v[j] - mean[j]) * istd[j];
                 }
             }
+        };
+        int64_t m = (int64_t)blockIdx.x * RL + rl;
+        float va[8], da[8], oa[8], vb[8], db[8], ob[8];
+        for (; m + stride < a.M; m += 2 * stride) {
+            fetch(m, va, da, oa);
+            fetch(m + stride, vb, db, ob);
+            add(va, da, oa);
+            add(vb, db, ob);
+        }
+        if (m < a.M) {
+            fetch(m, va, da, oa);
+            add(va, da, oa);
         }
     }
 #pragma unroll
