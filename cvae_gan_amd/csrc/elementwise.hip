@@ -667,7 +667,10 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
     bz = (int)(rest / gy);
 }
 
-// grid: x over (padded column, 8-channel chunk), y = padded row, z = image
+// grid: x over (padded column, 8-channel chunk), y = PAIR of padded rows (2k, 2k+1), z = image.  The two
+// rows of a pair interpolate between the same two source rows (padded row 2k is up-sampled row 2k-1 =
+// .75/.25 of rows k-1, k; padded row 2k+1 is up-sampled row 2k = .25/.75 of the same), so the four
+// source vectors are loaded once per pair.
 template <typename T>
 __global__ void __launch_bounds__(256) upsample_pad_fwd(const T* __restrict__ x, T* __restrict__ u, int B, int h, int w,
                                                         int C) {
@@ -677,20 +680,31 @@ __global__ void __launch_bounds__(256) upsample_pad_fwd(const T* __restrict__ x,
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= UW * CC) return;
     const int ux = t / CC, ch = t - ux * CC;
-    const int uy = blockIdx.y, b = blockIdx.z;
-    int y0, y1, x0, x1;
-    float wy0, wy1, wx0, wx1;
-    up_src(unpad_reflect1(uy, 2 * h), h, y0, y1, wy0, wy1);
+    const int uy0 = 2 * blockIdx.y, b = blockIdx.z;
+    int x0, x1;
+    float wx0, wx1;
     up_src(unpad_reflect1(ux, 2 * w), w, x0, x1, wx0, wx1);
     const T* base = x + (size_t)b * h * w * C + ch * 8;
     float a[8], bb[8], c[8], d[8], o[8];
-    load8<T>(base + ((size_t)y0 * w + x0) * C, a);
-    load8<T>(base + ((size_t)y0 * w + x1) * C, bb);
-    load8<T>(base + ((size_t)y1 * w + x0) * C, c);
-    load8<T>(base + ((size_t)y1 * w + x1) * C, d);
+    int ly0 = -1, ly1 = -1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * bb[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
-    store8<T>(u + (((size_t)b * UH + uy) * UW + ux) * C + ch * 8, o);
+    for (int r = 0; r < 2; ++r) {
+        const int uy = uy0 + r;
+        if (uy >= UH) break;
+        int y0, y1;
+        float wy0, wy1;
+        up_src(unpad_reflect1(uy, 2 * h), h, y0, y1, wy0, wy1);
+        if (y0 != ly0 || y1 != ly1) {             // uniform over the workgroup
+            load8<T>(base + ((size_t)y0 * w + x0) * C, a);
+            load8<T>(base + ((size_t)y0 * w + x1) * C, bb);
+            load8<T>(base + ((size_t)y1 * w + x0) * C, c);
+            load8<T>(base + ((size_t)y1 * w + x1) * C, d);
+            ly0 = y0; ly1 = y1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = wy0 * (wx0 * a[j] + wx1 * bb[j]) + wy1 * (wx0 * c[j] + wx1 * d[j]);
+        store8<T>(u + (((size_t)b * UH + uy) * UW + ux) * C + ch * 8, o);
+    }
 }
 
 // Per-axis taps of the transpose: which padded positions feed input index i, and with what weight.
@@ -1140,7 +1154,7 @@ int cvg_upsample_pad_fwd(const void* x, void* u, int32_t dtype, int32_t B, int32
                          cvg_stream stream) {
     CVG_CHECK(x && u && B > 0 && h > 0 && w > 0 && C % 8 == 0, "upsample_pad_fwd: bad args");
     CVG_CHECK(2 * h + 2 <= 65535 && B <= 65535, "upsample_pad_fwd: grid too large");
-    const dim3 grid(grid1((int64_t)(2 * w + 2) * (C / 8)), 2 * h + 2, B);
+    const dim3 grid(grid1((int64_t)(2 * w + 2) * (C / 8)), h + 1, B);
     DISPATCH(dtype, upsample_pad_fwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)u, B, h, w, C));
     CVG_LAUNCH_CHECK();
     return 0;
