@@ -550,21 +550,39 @@ __global__ void __launch_bounds__(1024) reparam_kl_fwd(const T* __restrict__ h, 
                                                        float batch_size) {
     __shared__ float red[16];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < B * zin_ld; i += blockDim.x) {
-        const int b = i / zin_ld, j = i % zin_ld;
-        float out = 0.f;
-        if (j < z) {
-            const float mu = to_f32(h[(size_t)b * 2 * z + j]);
-            const float ls = to_f32(h[(size_t)b * 2 * z + z + j]);
-            const float sg = expf(ls);
-            out = mu + sg * eps[b * z + j];
-            z_mean[b * z + j] = mu;
-            z_sigma[b * z + j] = sg;
-            acc += mu * mu + sg * sg - 2.f * ls - 1.f;     // log(sigma^2) = 2 * log_sigma
-        } else if (j < z + y_dim) {
-            out = labels[b] == j - z ? 1.f : 0.f;
+    // one workgroup (a fixed summation order for the KL term); four elements per thread are in flight
+    // at a time, or the few dozen dependent round trips of a plain loop take 30 us
+    const int n = B * z, NTH = blockDim.x;
+    for (int base = threadIdx.x; base < n; base += 4 * NTH) {
+        float mu[4], ls[4], ep[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NTH;
+            mu[u] = ls[u] = ep[u] = 0.f;
+            if (i < n) {
+                const int b = i / z, j = i - b * z;
+                mu[u] = to_f32(h[(size_t)b * 2 * z + j]);
+                ls[u] = to_f32(h[(size_t)b * 2 * z + z + j]);
+                ep[u] = eps[i];
+            }
         }
-        zin[i] = from_f32<T>(out);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NTH;
+            if (i >= n) continue;
+            const int b = i / z, j = i - b * z;
+            const float sg = expf(ls[u]);
+            zin[(size_t)b * zin_ld + j] = from_f32<T>(mu[u] + sg * ep[u]);
+            z_mean[i] = mu[u];
+            z_sigma[i] = sg;
+            acc += mu[u] * mu[u] + sg * sg - 2.f * ls[u] - 1.f;     // log(sigma^2) = 2 * log_sigma
+        }
+    }
+    // the one-hot label and the padding columns behind the latent
+    const int tail = zin_ld - z;
+    for (int i = threadIdx.x; i < B * tail; i += NTH) {
+        const int b = i / tail, j = z + (i - b * tail);
+        zin[(size_t)b * zin_ld + j] = from_f32<T>((j < z + y_dim && labels[b] == j - z) ? 1.f : 0.f);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
