@@ -480,13 +480,24 @@ __global__ void __launch_bounds__(256) per_image_colsum(const T* __restrict__ dy
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
     const T* base = dy + (size_t)blockIdx.x * pixels * C;
-    if (rl < RL)
-        for (int m = rl; m < pixels; m += RL) {
+    if (rl < RL) {
+        int m = rl;
+        for (; m + 3 * RL < pixels; m += 4 * RL) {      // four rows in flight (one workgroup per CU), summed in order
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8<T>(base + (size_t)(m + u * RL) * C + chunk * 8, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += v[u][j];
+        }
+        for (; m < pixels; m += RL) {
             float v[8];
             load8<T>(base + (size_t)m * C + chunk * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += v[j];
         }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) sm[threadIdx.x][j] = s[j];
     __syncthreads();
