@@ -21,10 +21,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 CONFIGS = {
-    # name: (pix_dim, y_dim, z_dim, per-GPU batch)   -- z_dim 32 from the reference's train.sh:6
-    "c2": (32, 10, 32, 256),
-    "c3": (64, 100, 32, 256),
-    "c4": (128, 100, 32, 64),
+    # name: (pix_dim, y_dim, z_dim, per-GPU batch, down/up stages)   -- z_dim 32 from the reference's train.sh:6
+    "c2": (32, 10, 32, 256, 4),
+    "c3": (64, 100, 32, 256, 4),
+    "c4": (128, 100, 32, 64, 4),
+    "c4d": (128, 100, 32, 64, 5),          # "deeper stacks": ndown = nup = 5 (networks.py:165, :133)
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
@@ -151,12 +152,12 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(P, y, z, seconds_budget=20.0):
+def cpu_baseline(P, y, z, n_stage=4, seconds_budget=20.0):
     """The CPU oracle (a port of the reference's step, pinned to the reference by the golden
     fixtures) timed on this host: fp32, B=32, same synthetic distribution."""
     from oracle import ref_cpu as O
     B = 32
-    e, d = O.init_params(P, y, z, seed=0)
+    e, d = O.init_params(P, y, z, seed=0, n_stage=n_stage)
     st = O.TrainState(e, d)
     g = torch.Generator().manual_seed(0)
     F = 4 * (z + y)
@@ -186,6 +187,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the config's batch is the GLOBAL batch, split over the ranks "
+                         "(the reference's nn.DataParallel semantics); default is weak scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--lr", type=float, default=3e-5)
@@ -213,12 +217,15 @@ def main():
     from cvae_gan_amd.engine import Engine
     from cvae_gan_amd import ddp
 
-    P, y, z, B = CONFIGS[args.config]
+    P, y, z, B, n_stage = CONFIGS[args.config]
     if args.batch:
         B = args.batch
+    if args.strong:
+        assert B % world == 0, "global batch %d does not split over %d ranks" % (B, world)
+        B //= world
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     note("process group up")
-    eng = Engine(P, y, z, B, dtype=dtype, seed=0)
+    eng = Engine(P, y, z, B, dtype=dtype, seed=0, n_stage=n_stage)
     ddp.broadcast_state(eng)
     note("state broadcast")
     batches = make_batches(eng, 4, 1234 + rank)
@@ -398,17 +405,18 @@ def main():
     out = {
         "metric": "train images/sec", "value": round(B * world * args.steps / dt, 1), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "CVAE train step (encoder+sampler+decoder fwd/bwd, KL+MSE, AdamW), %dx%dx3, %d classes, "
-                               "z_dim %d, per-GPU batch %d, random-init weights" % (P, P, y, z, B),
+                               "z_dim %d, %d down/up stages, per-GPU batch %d, random-init weights" % (P, P, y, z, n_stage, B),
                    "name": args.config, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "launch": "hip-graph" if use_graph else "eager"},
         "losses_last_step": {k: round(v, 6) for k, v in losses.items()},
         "roofline": roofline,
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(P, y, z)
+        out["cpu_baseline"] = cpu_baseline(P, y, z, n_stage)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

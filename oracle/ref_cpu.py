@@ -211,9 +211,17 @@ def down_block(sd, prefix, x, train, new_stats, taps=None):
     return out
 
 
-def encoder_forward(sd, x, planes, train=True, new_stats=None, taps=None, n_stage=N_STAGE):
+def count_stages(sd):
+    """Number of down blocks (encoder dict) or up stages (decoder dict) a state dict holds:
+    ndown / nup of models/networks.py:165, :133 (4 in the wrappers, :82 and :60)."""
+    return sum(1 for k in sd if (k.startswith(EP) and k.endswith(".conv.weight"))
+               or (k.startswith(DP) and k.endswith(".2.weight")))
+
+
+def encoder_forward(sd, x, planes, train=True, new_stats=None, taps=None, n_stage=None):
     """encoder.forward (models/networks.py:85-89) followed by ResNetEncoder.forward
     (models/networks.py:193-196).  x [B,3,P,P], planes [B,y,P,P] -> [B, 2z]."""
+    n_stage = n_stage or count_stages(sd)
     h = stem_conv(sd, torch.cat([x, planes], dim=1))
     if taps is not None:
         taps["stem"] = h
@@ -256,11 +264,12 @@ def upconv(sd, prefix, x):
     return F.conv2d(u, sd[prefix + "weight"], sd[prefix + "bias"])
 
 
-def decoder_forward(sd, z, y_vec, drop_mask=None, train=True, taps=None, n_stage=N_STAGE):
+def decoder_forward(sd, z, y_vec, drop_mask=None, train=True, taps=None, n_stage=None):
     """decoder.forward (models/networks.py:63-68) and ConvUpSampleDecoder.forward
     (models/networks.py:159-162).  drop_mask is the 0/1 keep mask of nn.Dropout(0.5)
     (models/networks.py:155); kept activations are scaled by 2.  In eval mode the
     dropout is the identity."""
+    n_stage = n_stage or count_stages(sd)
     h = torch.cat([z, y_vec], dim=1)
     g0 = F.linear(h, sd[DP + "fc.0.weight"], sd[DP + "fc.0.bias"])
     h = _lrelu(g0)

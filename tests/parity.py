@@ -53,13 +53,13 @@ def oracle_pass(case, step=0, state=None):
     acts = OrderedDict()
     acts["s0"] = et["stem"]
     acts["a0"] = et["a0"]
-    for i in range(4):
+    for i in range(case.n_stage):
         b = et["block%d" % i]
         for n in ("c1", "b1", "c2", "r", "out"):
             acts["blk%d.%s" % (i, n)] = b[n]
     acts["f0"], acts["f1"], acts["h"] = et["f0"], et["f1"], h
     acts["g0"], acts["g1"], acts["x0"] = dt["g0"], dt["g1"], dt["x0"]
-    for i in range(4):
+    for i in range(case.n_stage):
         acts["up%d" % i] = dt["up%d" % i]
     acts["pre"], acts["dec"] = dt["pre"], dec
     for t in acts.values():
@@ -76,7 +76,7 @@ def engine_pass(case, dtype, step=0, state=None):
     e, d = state if state is not None else case.init_state()
     st = OrderedDict(e)
     st.update(d)
-    eng = Engine(case.P, case.y, case.z, case.B, dtype=dtype, ngf=case.ngf, state=st)
+    eng = Engine(case.P, case.y, case.z, case.B, dtype=dtype, ngf=case.ngf, n_stage=case.n_stage, state=st)
     x, labels, eps, mask = case.inputs(step)
     eng.set_mask(mask)
     xd = x.cuda()

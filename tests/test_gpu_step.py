@@ -96,7 +96,7 @@ def test_three_steps_f32_match_golden():
     e, d = c.init_state()
     st = OrderedDict(e)
     st.update(d)
-    eng = Engine(c.P, c.y, c.z, c.B, dtype=torch.float32, ngf=c.ngf, state=st)
+    eng = Engine(c.P, c.y, c.z, c.B, dtype=torch.float32, ngf=c.ngf, n_stage=c.n_stage, state=st)
     for step in range(c.n_steps):
         x, labels, eps, mask = c.inputs(step)
         eng.set_mask(mask)

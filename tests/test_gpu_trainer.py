@@ -28,7 +28,7 @@ def test_eval_forward_matches_reference(name):
     c = Case(name)
     st = _after3_state(c)
     assert len(st) > 0
-    eng = Engine(c.P, c.y, c.z, c.B, dtype=torch.float32, ngf=c.ngf, state=st)
+    eng = Engine(c.P, c.y, c.z, c.B, dtype=torch.float32, ngf=c.ngf, n_stage=c.n_stage, state=st)
     eng.training = False
     x, labels, _, _ = c.inputs(c.n_steps - 1)
     eps = torch.from_numpy(c.npz["eval/eps"])

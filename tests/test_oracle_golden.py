@@ -96,7 +96,7 @@ def test_oracle_eval_mode_decoder():
     for name in ("tiny_p16_ngf8", "ragged_p32_ngf8"):
         c = Case(name)
         dec_sd = {k: torch.from_numpy(c.npz["after%d/%s" % (c.n_steps, k)])
-                  for k in O.param_shapes(c.P, c.y, c.z, ngf=c.ngf)[1]}
+                  for k in O.param_shapes(c.P, c.y, c.z, c.n_stage, c.ngf)[1]}
         zs = torch.from_numpy(c.npz["eval/z"])
         ys = torch.from_numpy(c.npz["eval/y"])
         out = O.decoder_forward(dec_sd, zs, ys, None, train=False)

@@ -85,7 +85,7 @@ class _Args:
     pass
 
 
-def build(N, P, y, z, seed, ngf, oracle_init):
+def build(N, P, y, z, seed, ngf, oracle_init, n_stage=4):
     """The reference's inner nets with the wrappers' ctor arguments
     (networks.py:82, :60; ngf is 64 there, smaller here for the tiny case).
     oracle_init=True overwrites the reference's own kaiming draw with
@@ -93,12 +93,12 @@ def build(N, P, y, z, seed, ngf, oracle_init):
     torch.manual_seed(seed)
     norm = N.get_norm_layer("batch")
     nl = N.get_non_linearity("lrelu")
-    enc = N.ResNetEncoder(P, 3 + y, 2 * z, ngf, 4, norm, nl)
-    dec = N.ConvUpSampleDecoder(P, z + y, ngf, 4, norm, nl)
+    enc = N.ResNetEncoder(P, 3 + y, 2 * z, ngf, n_stage, norm, nl)
+    dec = N.ConvUpSampleDecoder(P, z + y, ngf, n_stage, norm, nl)
     N.init_weights(enc, "kaiming")
     N.init_weights(dec, "kaiming")
     if oracle_init:
-        e, d = O.init_params(P, y, z, seed=seed, ngf=ngf)
+        e, d = O.init_params(P, y, z, seed=seed, ngf=ngf, n_stage=n_stage)
         enc.load_state_dict({k[len(O.EP):]: v for k, v in e.items()})
         dec.load_state_dict({k[len(O.DP):]: v for k, v in d.items()})
     return enc, dec
@@ -108,9 +108,9 @@ def sd_with_prefix(net, prefix):
     return {prefix + k: v.detach().clone().numpy() for k, v in net.state_dict().items()}
 
 
-def run_case(N, name, P, y, z, B, batch_size_flag, lr, seed, ngf, small, n_steps=3,
-             layer_taps=True):
-    enc, dec = build(N, P, y, z, seed, ngf, oracle_init=not small)
+def _run_case(N, name, P, y, z, B, batch_size_flag, lr, seed, ngf, small, n_steps=3,
+             layer_taps=True, n_stage=4):
+    enc, dec = build(N, P, y, z, seed, ngf, oracle_init=not small, n_stage=n_stage)
     args = _Args()
     args.z_dim, args.device = z, torch.device("cpu")
     model = N.CVAE_T(args, _EncAdapter(enc), _DecAdapter(dec))
@@ -118,8 +118,10 @@ def run_case(N, name, P, y, z, B, batch_size_flag, lr, seed, ngf, small, n_steps
     mse = torch.nn.MSELoss()
     model.train()
 
-    out = {"meta": np.array([P, y, z, B, batch_size_flag, n_steps, ngf, seed, int(small)],
-                            dtype=np.int64),
+    meta = [P, y, z, B, batch_size_flag, n_steps, ngf, seed, int(small)]
+    if n_stage != 4:
+        meta.append(n_stage)                # older fixtures have nine fields and mean four stages
+    out = {"meta": np.array(meta, dtype=np.int64),
            "lr": np.array(lr, dtype=np.float64)}
     if small:
         out.update({"init/" + k: v for k, v in sd_with_prefix(enc, "encoder.module.").items()})
@@ -220,6 +222,11 @@ def main():
     N = import_reference()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = sys.argv[1:]
+
+    def run_case(N, name, **kw):            # noqa: F811  (optional filter: names on the command line)
+        if not only or name in only:
+            _run_case(N, name, **kw)
     # tiny: P=16 is the smallest size the nets accept (pix_dim must be a multiple of
     # 16: networks.py:179, :136); ngf=8 keeps every tensor small enough to store whole.
     run_case(N, "tiny_p16_ngf8", P=16, y=4, z=8, B=4, batch_size_flag=4, lr=1e-3, seed=0,
@@ -231,6 +238,10 @@ def main():
     # oracle.init_params(seed), big tensors are stored as samples + moments.
     run_case(N, "c2_p32_ngf64", P=32, y=10, z=32, B=8, batch_size_flag=256, lr=1e-3, seed=2,
              ngf=64, small=False)
+    # five down / up stages instead of the wrappers' four (ndown, nup of networks.py:165, :133): the
+    # "deeper stacks" variant of the 128 x 128 configuration, here at 64 x 64 -> 2 x 2 with ngf=8
+    run_case(N, "deep5_p64_ngf8", P=64, y=5, z=8, B=4, batch_size_flag=4, lr=1e-3, seed=3,
+             ngf=8, small=True, layer_taps=False, n_stage=5)
 
 
 if __name__ == "__main__":
