@@ -38,6 +38,40 @@ def test_bad_descriptor_is_rejected_without_a_gpu():
     assert b"Cin" in _lib.lib.cvg_last_error()
 
 
+def _desc(**kw):
+    from cvae_gan_amd import _lib
+    d = _lib.ConvDesc()
+    base = dict(dtype=1, B=1, H=8, W=8, Cin=16, OH=8, OW=8, N=16, KW=3, ntaps=9, stride=1, tstep_y=1, tstep_x=1,
+                off_y=-1, off_x=-1, pad_mode=0, x_pix_pitch=16, x_row_pitch=8 * 16, x_img_pitch=64 * 16,
+                y_pix_pitch=16, y_row_pitch=8 * 16, y_img_pitch=64 * 16, oy_mul=1, ox_mul=1, w_ld=192, w_rows=128)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    return d
+
+
+def _rejected(d, needle):
+    from cvae_gan_amd import _lib
+    rc = _lib.lib.cvg_conv_fwd(C.byref(d), None, None, None, None, None, None, None, None, None, 0, None)
+    assert rc != 0
+    assert needle in _lib.lib.cvg_last_error(), _lib.lib.cvg_last_error()
+
+
+def test_size_and_padding_limits_are_rejected_without_a_gpu():
+    """The kernels index the gathered tensor with 32-bit element offsets and mirror a coordinate
+    once: a descriptor beyond either limit must fail in validation, never reach a launch."""
+    # 640 images of 130 x 130 x 256 (a padded 128 x 128 map) = 2.77e9 elements
+    _rejected(_desc(B=640, H=130, W=130, Cin=256, OH=128, OW=128, x_pix_pitch=256, x_row_pitch=130 * 256,
+                    x_img_pitch=130 * 130 * 256), b"32-bit")
+    # reflection by 3 into a 2-pixel-wide tensor needs two reflections
+    _rejected(_desc(H=2, W=2, OH=2, OW=2, KW=7, ntaps=49, off_y=-3, off_x=-3, pad_mode=1, x_row_pitch=2 * 16,
+                    x_img_pitch=4 * 16), b"reflection")
+    # channels per tap must be a power of two when there is more than one tap
+    _rejected(_desc(Cin=24, x_pix_pitch=24, x_row_pitch=8 * 24, x_img_pitch=64 * 24), b"power of two")
+    # a null tensor with an otherwise valid descriptor
+    _rejected(_desc(), b"null tensor")
+
+
 def test_struct_layout_matches_header():
     from cvae_gan_amd import _lib
     assert C.sizeof(_lib.ConvDesc) == 28 * 4
