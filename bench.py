@@ -197,6 +197,12 @@ def main():
     args = ap.parse_args()
 
     trace = os.environ.get("CVG_BENCH_TRACE") is not None
+    # Libraries write to file descriptor 1 behind Python's back (RCCL prints a version banner there
+    # when its first communicator comes up).  stdout must carry the one JSON line only: everything
+    # else goes to stderr, and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     def note(msg):
         if trace:
@@ -213,6 +219,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=backend)
+
+    if world == 1 and os.environ.get("CVG_BENCH_FORCE_DDP") == "nccl":
+        # rehearsal of the N > 1 schedule on one GPU with real RCCL calls (a one-rank group)
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500),
+                                rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     from cvae_gan_amd.engine import Engine
     from cvae_gan_amd import ddp
@@ -251,7 +262,7 @@ def main():
         ev.record()
         with torch.cuda.stream(comm):
             comm.wait_event(ev)
-            if world > 1 and dist.get_backend() == "nccl":
+            if dist.is_initialized() and dist.get_backend() == "nccl":
                 dist.all_reduce(eng.g_arena[lo:hi], op=dist.ReduceOp.SUM)
             elif world > 1:                  # rehearsal backends reduce a host copy
                 comm.synchronize()
@@ -417,8 +428,9 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(P, y, z, n_stage)
-    print(json.dumps(out))
-    if world > 1:
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
