@@ -315,15 +315,18 @@ def main():
         else:
             g_head, g_enc, g_enc2, g_opt = (torch.cuda.CUDAGraph() for _ in range(4))
             pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g_head, pool=pool):
+            # thread-local capture mode: the process group's watchdog thread polls events while this
+            # thread captures, which the default (global) mode would treat as a capture violation
+            tl = {"pool": pool, "capture_error_mode": "thread_local"}
+            with torch.cuda.graph(g_head, **tl):
                 eng.random_mask()
                 eng._packed_version = -1
                 eng.forward_backward_decoder(gx, gl, ge, batch_size_flag, loss_scale)
-            with torch.cuda.graph(g_enc, pool=pool):
+            with torch.cuda.graph(g_enc, **tl):
                 eng.enc_backward(eng.enc["dh"], part="upper")
-            with torch.cuda.graph(g_enc2, pool=pool):
+            with torch.cuda.graph(g_enc2, **tl):
                 eng.enc_backward(eng.enc["dh"], part="lower")
-            with torch.cuda.graph(g_opt, pool=pool):
+            with torch.cuda.graph(g_opt, **tl):
                 eng.adamw_step(args.lr)
 
             def run_graphs():
