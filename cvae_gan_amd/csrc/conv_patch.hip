@@ -75,6 +75,30 @@ __device__ __forceinline__ int lane_pixel(int l31, int permute) {
     return l31;                             // 28..31 -> 28..31
 }
 
+// One staged 16-byte piece plus its residual term: v + r * LeakyReLU'(g) per element (g > 0 ? 1 : slope;
+// no gate: v + r), in f32, rounded once more to T.
+template <typename T> __device__ __forceinline__ u32x4 add_gated(u32x4 v, u32x4 r, u32x4 g, bool gated);
+template <> __device__ __forceinline__ u32x4 add_gated<float>(u32x4 v, u32x4 r, u32x4 g, bool gated) {
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float rv = __uint_as_float(r[j]);
+        const float k = (!gated || __uint_as_float(g[j]) > 0.f) ? 1.f : LRELU_SLOPE;
+        o[j] = __float_as_uint(__uint_as_float(v[j]) + rv * k);
+    }
+    return o;
+}
+template <> __device__ __forceinline__ u32x4 add_gated<bf16>(u32x4 v, u32x4 r, u32x4 g, bool gated) {
+    const bf16x8 vb = __builtin_bit_cast(bf16x8, v), rb = __builtin_bit_cast(bf16x8, r), gb = __builtin_bit_cast(bf16x8, g);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float k = (!gated || (float)gb[j] > 0.f) ? 1.f : LRELU_SLOPE;
+        o[j] = (__bf16)((float)vb[j] + (float)rb[j] * k);
+    }
+    return __builtin_bit_cast(u32x4, o);
+}
+
 // ======================================================================================
 // forward
 // ======================================================================================
@@ -200,40 +224,6 @@ patch_fwd(const PatchFwdArgs a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-    // A residual term (res * LeakyReLU'(gate), the skip branch of a res block's input gradient)
-    // starts the accumulators: its scattered 8-byte reads are in flight while the first patch and
-    // the weight ring fill, instead of sitting in the epilogue.
-    if (a.res && !a.scale) {
-        const T* __restrict__ resp = (const T*)a.res;
-        const T* __restrict__ gatep = (const T*)a.gate;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int ql = wm * WTM + mi * 32 + lane_pixel(l31, a.lane_perm);
-            int tb, ty, tx;
-            tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
-            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-            if (!(ql < t.npx && b < a.B && oy < a.OH && ox < a.OW)) continue;
-            const int yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int n = n0 + wn * WTN + ni * 32 + 8 * g4 + 4 * h;
-                    if (n >= a.N) continue;
-                    float r[4];
-                    load4<T>(resp + yoff + n, r);
-                    if (gatep) {
-                        float gt[4];
-                        load4<T>(gatep + yoff + n, gt);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] *= gt[j] > 0.f ? 1.f : LRELU_SLOPE;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g4 + j] = r[j];
-                }
-        }
-    }
-
 #ifdef EXP_TIMING
     long long tp[3];
     tp[0] = __builtin_readcyclecounter();
@@ -313,6 +303,60 @@ patch_fwd(const PatchFwdArgs a) {
     tt[2] = __builtin_readcyclecounter();
 #endif
     constexpr int OP = BN * ES + 16;             // staged row pitch
+    // Mapping of the second half (below): thread -> (16-byte piece pc of the staged row, PT consecutive
+    // tile pixels).  It is set up here, before the staging, so that a residual term (res *
+    // LeakyReLU'(gate): the skip branch of a res block's input gradient) can be requested now, as whole
+    // 16-byte pieces on consecutive lanes, and arrive while the accumulators go through LDS.
+    T* __restrict__ yp = (T*)a.y;
+    constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
+    constexpr int BMT = WM * WTM;
+    constexpr int EPP = 16 / ES;                 // elements per piece
+    constexpr int PT = BMT * PPR / NT;           // pixels per thread
+    const int pc = tid % PPR, q0 = (tid / PPR) * PT;
+    const int n_out = n0 + pc * EPP;
+    const bool whole = n_out + EPP <= a.N;       // else N is a multiple of 4: half a 16-bit piece
+    int yo[PT];                                  // element offset of pixel q0 + i in y, -1: not stored
+    if (a.row_fast) {                            // the PT pixels share one output row
+        int tb, ty, tx;
+        tile_px(t, q0 < t.npx ? q0 : 0, tb, ty, tx);
+        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+        const bool ok = n_out < a.N && q0 < t.npx && b < a.B && oy < a.OH;
+        const int step = a.ox_mul * a.y_pix_pitch;
+        int yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            yo[i] = (ok && ox + i < a.OW) ? yoff + n_out : -1;
+            yoff += step;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int q = q0 + i;
+            int tb, ty, tx;
+            tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
+            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            const bool ok = n_out < a.N && q < t.npx && b < a.B && oy < a.OH && ox < a.OW;
+            yo[i] = ok ? b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
+        }
+    }
+    const bool res_mode = a.res && !a.scale;
+    u32x4 rr[PT], gg[PT];
+    if (res_mode) {
+        const T* __restrict__ resp = (const T*)a.res;
+        const T* __restrict__ gatep = a.gate ? (const T*)a.gate : resp;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {           // branch-free: pixels that are not stored read element 0
+            const int o = yo[i] >= 0 ? yo[i] : 0;
+            if (whole || yo[i] < 0) {
+                rr[i] = *(const u32x4*)(resp + o);
+                gg[i] = *(const u32x4*)(gatep + o);
+            } else {
+                const unsigned long long r8 = *(const unsigned long long*)(resp + o), g8 = *(const unsigned long long*)(gatep + o);
+                rr[i] = u32x4{(unsigned)r8, (unsigned)(r8 >> 32), 0u, 0u};
+                gg[i] = u32x4{(unsigned)g8, (unsigned)(g8 >> 32), 0u, 0u};
+            }
+        }
+    }
     const bool per_pixel = a.cbias != nullptr;   // the class bias needs the pixel's image
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -380,54 +424,20 @@ patch_fwd(const PatchFwdArgs a) {
         }
     };
 #endif
-    // Second half: thread -> (16-byte piece pc of the row, PT consecutive tile pixels).  When the tile
-    // rows hold a multiple of PT pixels (a.row_fast) the PT pixels share one output row: one address
-    // computation, then a fixed step per pixel.
-    T* __restrict__ yp = (T*)a.y;
-    constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
-    constexpr int BMT = WM * WTM;
-    constexpr int EPP = 16 / ES;                 // elements per piece
-    constexpr int PT = BMT * PPR / NT;           // pixels per thread
-    const int pc = tid % PPR, q0 = (tid / PPR) * PT;
-    const int n = n0 + pc * EPP;
-    if (n >= a.N) return;
-    const bool whole = n + EPP <= a.N;           // else N is a multiple of 4: half a 16-bit piece
-    auto put = [&](int q, int yoff) __attribute__((always_inline)) {
-        const u32x4 v = *(const u32x4*)(smem + q * OP + pc * 16);
-        if (whole) *(u32x4*)(yp + yoff + n) = v;
-        else *(unsigned long long*)(yp + yoff + n) = ((unsigned long long)v[1] << 32) | v[0];
-    };
-    if (a.row_fast) {
-        if (q0 >= t.npx) return;
-        int tb, ty, tx;
-        tile_px(t, q0, tb, ty, tx);
-        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-        if (b >= a.B || oy >= a.OH) return;
-        const int step = a.ox_mul * a.y_pix_pitch;
-        int yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+    // Second half: whole pixel rows leave LDS, 16 bytes per lane, consecutive lanes on consecutive
+    // addresses; the residual term joins here.
+    const bool gated = a.gate != nullptr;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            if (ox + i < a.OW) put(q0 + i, yoff);
-            yoff += step;
-        }
-#ifdef EXP_TIMING
-        finish();
-#endif
-    } else {
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int q = q0 + i;
-            if (q >= t.npx) continue;
-            int tb, ty, tx;
-            tile_px(t, q, tb, ty, tx);
-            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-            if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
-            put(q, b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch);
-        }
-#ifdef EXP_TIMING
-        finish();
-#endif
+    for (int i = 0; i < PT; ++i) {
+        if (yo[i] < 0) continue;
+        u32x4 v = *(const u32x4*)(smem + (q0 + i) * OP + pc * 16);
+        if (res_mode) v = add_gated<T>(v, rr[i], gg[i], gated);
+        if (whole) *(u32x4*)(yp + yo[i]) = v;
+        else *(unsigned long long*)(yp + yo[i]) = ((unsigned long long)v[1] << 32) | v[0];
     }
+#ifdef EXP_TIMING
+    finish();
+#endif
 }
 
 // weights -> fragment order: element ((nblk * nk2*2 + kstep) * 64 + lane) * 8 + j holds
