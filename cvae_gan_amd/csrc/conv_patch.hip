@@ -76,25 +76,29 @@ __device__ __forceinline__ int lane_pixel(int l31, int permute) {
 }
 
 // One staged 16-byte piece plus its residual term: v + r * LeakyReLU'(g) per element (g > 0 ? 1 : slope;
-// no gate: v + r), in f32, rounded once more to T.
-template <typename T> __device__ __forceinline__ u32x4 add_gated(u32x4 v, u32x4 r, u32x4 g, bool gated);
-template <> __device__ __forceinline__ u32x4 add_gated<float>(u32x4 v, u32x4 r, u32x4 g, bool gated) {
+// no gate: v + r), then LeakyReLU if act; in f32, rounded once more to T.
+template <typename T> __device__ __forceinline__ u32x4 add_gated(u32x4 v, u32x4 r, u32x4 g, bool gated, bool act);
+template <> __device__ __forceinline__ u32x4 add_gated<float>(u32x4 v, u32x4 r, u32x4 g, bool gated, bool act) {
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float rv = __uint_as_float(r[j]);
         const float k = (!gated || __uint_as_float(g[j]) > 0.f) ? 1.f : LRELU_SLOPE;
-        o[j] = __float_as_uint(__uint_as_float(v[j]) + rv * k);
+        float f = __uint_as_float(v[j]) + rv * k;
+        if (act) f = f > 0.f ? f : LRELU_SLOPE * f;
+        o[j] = __float_as_uint(f);
     }
     return o;
 }
-template <> __device__ __forceinline__ u32x4 add_gated<bf16>(u32x4 v, u32x4 r, u32x4 g, bool gated) {
+template <> __device__ __forceinline__ u32x4 add_gated<bf16>(u32x4 v, u32x4 r, u32x4 g, bool gated, bool act) {
     const bf16x8 vb = __builtin_bit_cast(bf16x8, v), rb = __builtin_bit_cast(bf16x8, r), gb = __builtin_bit_cast(bf16x8, g);
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float k = (!gated || (float)gb[j] > 0.f) ? 1.f : LRELU_SLOPE;
-        o[j] = (__bf16)((float)vb[j] + (float)rb[j] * k);
+        float f = (float)vb[j] + (float)rb[j] * k;
+        if (act) f = f > 0.f ? f : LRELU_SLOPE * f;
+        o[j] = (__bf16)f;
     }
     return __builtin_bit_cast(u32x4, o);
 }
@@ -339,38 +343,35 @@ patch_fwd(const PatchFwdArgs a) {
             yo[i] = ok ? b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
         }
     }
-    const bool res_mode = a.res && !a.scale;
+    const bool res_mode = a.res != nullptr;      // with a.scale: y = act(scale * conv + shift + res)
     u32x4 rr[PT], gg[PT];
     if (res_mode) {
         const T* __restrict__ resp = (const T*)a.res;
-        const T* __restrict__ gatep = a.gate ? (const T*)a.gate : resp;
+        auto fetch = [&](const T* __restrict__ src, u32x4 (&dst)[PT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {           // branch-free: pixels that are not stored read element 0
-            const int o = yo[i] >= 0 ? yo[i] : 0;
-            if (whole || yo[i] < 0) {
-                rr[i] = *(const u32x4*)(resp + o);
-                gg[i] = *(const u32x4*)(gatep + o);
-            } else {
-                const unsigned long long r8 = *(const unsigned long long*)(resp + o), g8 = *(const unsigned long long*)(gatep + o);
-                rr[i] = u32x4{(unsigned)r8, (unsigned)(r8 >> 32), 0u, 0u};
-                gg[i] = u32x4{(unsigned)g8, (unsigned)(g8 >> 32), 0u, 0u};
+            for (int i = 0; i < PT; ++i) {       // branch-free: pixels that are not stored read element 0
+                const int o = yo[i] >= 0 ? yo[i] : 0;
+                if (whole || yo[i] < 0) {
+                    dst[i] = *(const u32x4*)(src + o);
+                } else {
+                    const unsigned long long r8 = *(const unsigned long long*)(src + o);
+                    dst[i] = u32x4{(unsigned)r8, (unsigned)(r8 >> 32), 0u, 0u};
+                }
             }
-        }
+        };
+        fetch(resp, rr);
+        if (a.gate) fetch((const T*)a.gate, gg);
     }
     const bool per_pixel = a.cbias != nullptr;   // the class bias needs the pixel's image
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int ql = wm * WTM + mi * 32 + lpx;
         const float* cb = nullptr;
-        const T* rs = nullptr;                   // residual row of this pixel (scaled-epilogue mode only)
-        if (per_pixel || (a.scale && a.res)) {
+        if (per_pixel) {
             int tb, ty, tx;
             tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
-            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
-            if (per_pixel && ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
-            if (a.scale && a.res && ql < t.npx && b < a.B && oy < a.OH && ox < a.OW)
-                rs = (const T*)a.res + (b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
-                                        (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch);
+            const int b = b0 + tb;
+            if (ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -389,16 +390,10 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += cb[n + j];
                     }
-                    if (a.scale) {               // y = act(scale * conv + shift + res)
+                    if (a.scale) {               // y = act(scale * conv + shift [+ res: second half])
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = v[j] * a.scale[n + j] + a.shift[n + j];
-                        if (rs) {
-                            float r[4];
-                            load4<T>(rs + n, r);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += r[j];
-                        }
-                        if (a.act) {
+                        if (a.act && !res_mode) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : LRELU_SLOPE * v[j];
                         }
@@ -431,7 +426,7 @@ patch_fwd(const PatchFwdArgs a) {
     for (int i = 0; i < PT; ++i) {
         if (yo[i] < 0) continue;
         u32x4 v = *(const u32x4*)(smem + (q0 + i) * OP + pc * 16);
-        if (res_mode) v = add_gated<T>(v, rr[i], gg[i], gated);
+        if (res_mode) v = add_gated<T>(v, rr[i], gg[i], gated, a.scale && a.act);
         if (whole) *(u32x4*)(yp + yo[i]) = v;
         else *(unsigned long long*)(yp + yo[i]) = ((unsigned long long)v[1] << 32) | v[0];
     }
