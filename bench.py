@@ -78,7 +78,7 @@ class KernelTimer:
         es = 2 if eng.dtype == torch.bfloat16 else 4
 
         # HBM-bound passes, algorithmic bytes: BatchNorm forward = statistics (1 read) + apply (1 read,
-        # + the residual, 1 write); backward = two passes over dy, x (and y at residual sites) + 1 write
+        # + the residual, 1 write); backward = two passes over dy, x (and y where the gate is read from it) + 1 write
         def bn(x, res, y, M, C, stats, prefix):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -86,10 +86,10 @@ class KernelTimer:
             b.record()
             self.hbm.append(("batchnorm+lrelu forward (statistics, apply)", M * C * es * (3 + (res is not None)), a, b))
 
-        def bn_bwd(dy, y, x, dx, M, C, stats, prefix):
+        def bn_bwd(dy, y, x, dx, M, C, stats, prefix, **kw):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            self._bn_bwd(dy, y, x, dx, M, C, stats, prefix)
+            self._bn_bwd(dy, y, x, dx, M, C, stats, prefix, **kw)
             b.record()
             self.hbm.append(("batchnorm+lrelu backward (sums, dx)", M * C * es * (2 * (2 + (y is not None)) + 1), a, b))
 

@@ -55,7 +55,7 @@ def _load():
         "cvg_last_error": (C.c_char_p, []),
         "cvg_conv_fwd_workspace": (sz, [P(ConvDesc)]),
         "cvg_conv_fwd": (C.c_int, [P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-        "cvg_conv_fwd_group": (C.c_int, [i32, P(ConvDesc), vp, P(vp), vp, vp]),
+        "cvg_conv_fwd_group": (C.c_int, [i32, P(ConvDesc), vp, P(vp), vp, vp, vp]),
         "cvg_conv_wgrad_workspace": (sz, [P(ConvDesc)]),
         "cvg_conv_fwd_kernel": (C.c_char_p, [P(ConvDesc)]),
         "cvg_conv_wgrad_kernel": (C.c_char_p, [P(ConvDesc)]),

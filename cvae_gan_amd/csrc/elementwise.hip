@@ -12,7 +12,8 @@ __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLO
 
 // ---- column reductions over rows[M][ld] ----------------------------------------------
 // Thread layout: chunk = tid % CC handles 8 channels, rl = tid / CC strides the rows.
-enum { RED_STATS = 0, RED_BNBWD = 1, RED_SUM = 2, RED_BNBWD_X = 3 };   // _X: gate recomputed from x, y not read
+enum { RED_STATS = 0, RED_BNBWD = 1, RED_SUM = 2, RED_BNBWD_X = 3, RED_BNBWD_PLAIN = 4 };
+// _X: gate recomputed from x, y not read; _PLAIN: dy already carries the activation's derivative
 
 struct RedArgs {
     const void* x;       // STATS/SUM: input rows; BNBWD: conv output x
@@ -38,7 +39,8 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
     float mean[8], istd[8], sc[8], sh[8];
     constexpr bool from_x = MODE == RED_BNBWD_X;
-    if (MODE == RED_BNBWD || from_x) {
+    constexpr bool plain = MODE == RED_BNBWD_PLAIN;
+    if (MODE == RED_BNBWD || from_x || plain) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c_off + chunk * 8 + j;
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     if (rl < RL) {
         // two rows per trip: their loads are issued together (twice the bytes in flight per thread),
         // the sums are taken in row order, so the result does not depend on the pairing
-        const int NQ = (MODE == RED_BNBWD) ? 3 : (MODE == RED_BNBWD_X ? 2 : 1);
+        const int NQ = (MODE == RED_BNBWD) ? 3 : ((MODE == RED_BNBWD_X || plain) ? 2 : 1);
         const int64_t stride = (int64_t)gridDim.x * RL;
         auto fetch = [&](int64_t m, float (&v)[8], float (&d)[8], float (&o)[8]) {
             const size_t off = (size_t)m * a.ld + c_off + chunk * 8;
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
+                    const float g = (plain || o[j] > 0.f) ? d[j] : LRELU_SLOPE * d[j];
                     s0[j] += g;
                     s1[j] += g * (v[j] - mean[j]) * istd[j];
                 }
@@ -205,12 +207,14 @@ __global__ void __launch_bounds__(256) bn_act_fwd(const T* __restrict__ x, const
     }
 }
 
-template <typename T, bool from_x>   // from_x: gate = sign of gamma*xhat + beta, recomputed as bn_act_fwd does
+// GATE 0: sign of y; 1: sign of gamma*xhat + beta, recomputed as bn_act_fwd does; 2: none (dy is already gated)
+template <typename T, int GATE>
 __global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, const T* __restrict__ y,
                                                      const T* __restrict__ x, T* __restrict__ dx, int M, int C,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    constexpr bool from_x = GATE == 1;
     const int CC = C / 8, RL = blockDim.x / CC;
     const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
     if (rl >= RL) return;
@@ -234,12 +238,12 @@ __global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, c
         if (from_x) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = v[j] * k0[j] + sh[j];
-        } else {
+        } else if (GATE == 0) {
             load8<T>(y + off, o);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float g = o[j] > 0.f ? d[j] : LRELU_SLOPE * d[j];
+            const float g = (GATE == 2 || o[j] > 0.f) ? d[j] : LRELU_SLOPE * d[j];
             const float xh = (v[j] - mean[j]) * istd[j];
             v[j] = k0[j] * (g - k1[j] - xh * k2[j]);
         }
@@ -1075,24 +1079,24 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
                    cvg_stream stream) {
     if (check_rows("bn_act_bwd", M, C)) return -1;
     CVG_CHECK(dy && x && dx && stats && gamma && dgamma && dbeta && ws, "bn_act_bwd: null");
-    CVG_CHECK(y || beta, "bn_act_bwd: without y the gate needs beta");
     hipStream_t s = (hipStream_t)stream;
     RedArgs a = {x, dy, y, stats, gamma, beta, ws, M, C, C, red_blocks(M, C), C};
-    if (y) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
-    else DISPATCH(dtype, colreduce<T, RED_BNBWD_X><<<a.nblk, red_threads(C), 0, s>>>(a));
+    const int gate = y ? 0 : (beta ? 1 : 2);     // no y and no beta: dy is already gated
+    if (gate == 0) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
+    else if (gate == 1) DISPATCH(dtype, colreduce<T, RED_BNBWD_X><<<a.nblk, red_threads(C), 0, s>>>(a));
+    else DISPATCH(dtype, colreduce<T, RED_BNBWD_PLAIN><<<a.nblk, red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
     CVG_LAUNCH_CHECK();
     const int RL = 256 / (C / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
     if (nb > 4096) nb = 4096;
-    if (y) {
-        DISPATCH(dtype, bn_act_bwd_dx<T, false><<<nb, red_threads(C), 0, s>>>((const T*)dy, (const T*)y, (const T*)x, (T*)dx,
-                                                                              M, C, stats, gamma, beta, dgamma, dbeta));
-    } else {
-        DISPATCH(dtype, bn_act_bwd_dx<T, true><<<nb, red_threads(C), 0, s>>>((const T*)dy, nullptr, (const T*)x, (T*)dx,
-                                                                             M, C, stats, gamma, beta, dgamma, dbeta));
-    }
+#define BN_DX(G) DISPATCH(dtype, bn_act_bwd_dx<T, G><<<nb, red_threads(C), 0, s>>>((const T*)dy, (const T*)y, (const T*)x, \
+                                                                                 (T*)dx, M, C, stats, gamma, beta, dgamma, dbeta))
+    if (gate == 0) BN_DX(0);
+    else if (gate == 1) BN_DX(1);
+    else BN_DX(2);
+#undef BN_DX
     CVG_LAUNCH_CHECK();
     return 0;
 }

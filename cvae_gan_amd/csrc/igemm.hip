@@ -66,6 +66,23 @@ __device__ __forceinline__ bool pad_coord(const Geom& g, int& iy, int& ix) {
 // ================================================================================
 // forward / input-gradient kernel
 // ================================================================================
+// One staged 16-byte piece times LeakyReLU'(g) per element (g > 0 ? 1 : slope), rounded once more to T.
+template <typename T> __device__ __forceinline__ u32x4 mul_gate(u32x4 v, u32x4 g);
+template <> __device__ __forceinline__ u32x4 mul_gate<float>(u32x4 v, u32x4 g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(__uint_as_float(g[j]) > 0.f)) v[j] = __float_as_uint(__uint_as_float(v[j]) * LRELU_SLOPE);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 mul_gate<bf16>(u32x4 v, u32x4 g) {
+    bf16x8 vb = __builtin_bit_cast(bf16x8, v);
+    const bf16x8 gb = __builtin_bit_cast(bf16x8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (!((float)gb[j] > 0.f)) vb[j] = (__bf16)((float)vb[j] * LRELU_SLOPE);
+    return __builtin_bit_cast(u32x4, vb);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zsplit) {
     constexpr int VEC = Elem<T>::VEC;
@@ -254,7 +271,13 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
         const uint32_t ox = rem - oy * g.OW;
         const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
                             (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
-        const u32x4 v = *(const u32x4*)(smem + ml * OP + pc * 16);
+        u32x4 v = *(const u32x4*)(smem + ml * OP + pc * 16);
+        if (gatep && !resp) {                    // output gating: y = conv * LeakyReLU'(gate)
+            u32x4 gq = {0u, 0u, 0u, 0u};
+            if (n + EPP <= a.N) gq = *(const u32x4*)(gatep + yoff + n);
+            else { const unsigned long long g8 = *(const unsigned long long*)(gatep + yoff + n); gq[0] = (unsigned)g8; gq[1] = (unsigned)(g8 >> 32); }
+            v = mul_gate<T>(v, gq);
+        }
         if (n + EPP <= a.N) {
             *(u32x4*)(yp + yoff + n) = v;
         } else {                                 // N is a multiple of 4: half a 16-bit piece
@@ -632,7 +655,6 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     CVG_CHECK(d->w_rows % 128 == 0 && d->w_rows >= d->N, "conv_fwd: w_rows %d must be N padded to 128", d->w_rows);
     CVG_CHECK(x && w && y, "conv_fwd: null tensor");
     CVG_CHECK(!cbias || labels, "conv_fwd: cbias needs labels");
-    CVG_CHECK(!gate || res, "conv_fwd: gate needs res");
     CVG_CHECK(d->y_pix_pitch % 4 == 0 && d->y_row_pitch % 4 == 0 && d->y_img_pitch % 4 == 0, "conv_fwd: y pitches");
     const bool dense = fwd_dense_out(d) && !res && !cbias;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels; a.res = res; a.gate = gate;
@@ -640,13 +662,14 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
     hipStream_t s = (hipStream_t)stream;
-    if (patch_enabled()) {
+    const bool gate_only = gate && !res;         // y = conv * LeakyReLU'(gate): gather kernel, no split-K
+    if (patch_enabled() && !gate_only) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
         if (pp.ok) return patch_fwd_launch(d, pp, x, w, y, bias, cbias, labels, res, gate, s);
     }
     a.nk_total = ceil_div(a.g.Kvalid, BK);
-    a.ksplit = fwd_ksplit(d, a.g.M, dense);
+    a.ksplit = gate_only ? 1 : fwd_ksplit(d, a.g.M, dense);
     a.nk_per_split = ceil_div(a.nk_total, a.ksplit);
     a.ksplit = ceil_div(a.nk_total, a.nk_per_split);
     if (a.ksplit > 1)
@@ -668,7 +691,7 @@ int cvg_conv_bn_act_fwd(const cvg_conv_desc* d, const void* x, const void* w, vo
 }
 
 int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x, const void* const* w, void* y,
-                       cvg_stream stream) {
+                       const void* gate, cvg_stream stream) {
     CVG_CHECK(n >= 1 && n <= 4 && descs && x && w && y, "conv_fwd_group: bad args");
     FwdArgsGroup m;
     const cvg_conv_desc* d0 = &descs[0];
@@ -690,7 +713,7 @@ int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x, con
             CVG_CHECK(!pp.ok, "conv_fwd_group: member %d belongs to the patch kernel", i);
         }
         a.x = x; a.w = w[i]; a.y = y; a.bias = nullptr; a.cbias = nullptr; a.labels = nullptr; a.res = nullptr;
-        a.gate = nullptr; a.ws = nullptr; a.N = d->N; a.w_ld = d->w_ld;
+        a.gate = gate; a.ws = nullptr; a.N = d->N; a.w_ld = d->w_ld;
         a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
         a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
         a.nk_total = ceil_div(a.g.Kvalid, BK);

@@ -587,14 +587,15 @@ class Engine:
         self._fwd(g, x, conv_out, bias=bias, **kw)
         self._bn(conv_out, res, y, M, C, stats, prefix)
 
-    def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix):
-        """y=None for a BatchNorm without a residual input: the gate is recomputed from x."""
+    def _bn_bwd(self, dy, y, x, dx, M, C, stats, prefix, gated=False):
+        """y=None for a BatchNorm without a residual input: the gate is recomputed from x;
+        gated=True: dy is already the gradient of the BatchNorm's output."""
         if self._frozen:        # parameters are constants in this pass: dgamma / dbeta only serve dx
             dg, db = self._bn_scratch[0][:C], self._bn_scratch[1][:C]
         else:
             dg, db = self.grads[prefix + ".weight"], self.grads[prefix + ".bias"]
         ops.bn_act_bwd(dy, y, x, dx, M, C, stats, self.params[prefix + ".weight"], dg, db, self.red_ws,
-                       beta=self.params[prefix + ".bias"])
+                       beta=None if gated else self.params[prefix + ".bias"])
 
     def _ready(self, stage):
         if self.grad_ready is not None:
@@ -720,8 +721,10 @@ class Engine:
         p, M, C = blk["prefix"], blk["M"], blk["cin"]
         with self._branch():
             self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
-        blk["dgd_group"].run(blk["d_out"], blk["d_r"])
-        self._bn_bwd(blk["d_r"], blk["r"], blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4")
+        # d_r: gradient of the block's pre-activation sum (the stride-2 input gradient times
+        # LeakyReLU'(r), applied as that kernel stores): r is read once, not by all three consumers
+        blk["dgd_group"].run(blk["d_out"], blk["d_r"], gate=blk["r"])
+        self._bn_bwd(blk["d_r"], None, blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4", gated=True)
         with self._branch():
             self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)
         self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"])
@@ -729,8 +732,8 @@ class Engine:
         with self._branch():
             self._wgrad(blk["conv1"], blk["xin"], blk["d_c1"], C)
         d_xin = e["d_a0"] if i == 0 else e["blocks"][i - 1]["d_out"]
-        # d_xin = conv1^T(d_c1) + d_r * lrelu'(r)   (the residual branch)
-        self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"], gate=blk["r"])
+        # d_xin = conv1^T(d_c1) + d_r   (the residual branch)
+        self._fwd(blk["dg1"][0], blk["d_c1"], d_xin, res=blk["d_r"])
         self._ready("enc.blk%d" % i)
 
     def _enc_backward_stem(self, input_grad):

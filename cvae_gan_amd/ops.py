@@ -56,8 +56,9 @@ class ConvGroup:
         self.w = (C.c_void_p * self.n)(*[ptr(w) for w in weights])
         self._keep = weights
 
-    def run(self, x, y):
-        check(lib.cvg_conv_fwd_group(self.n, self.descs, ptr(x), self.w, ptr(y), stream()))
+    def run(self, x, y, gate=None):
+        """gate (laid out as y): y = conv * LeakyReLU'(gate)."""
+        check(lib.cvg_conv_fwd_group(self.n, self.descs, ptr(x), self.w, ptr(y), ptr(gate), stream()))
 
 
 def conv_wgrad_workspace(desc):
@@ -138,7 +139,8 @@ def bn_act_fwd(x, res, y, M, C_, stats, gamma, beta):
 
 
 def bn_act_bwd(dy, y, x, dx, M, C_, stats, gamma, dgamma, dbeta, ws, beta=None):
-    """y=None (with beta): the activation's sign is recomputed from x instead of read from y."""
+    """y=None with beta: the activation's sign is recomputed from x instead of read from y;
+    y=None without beta: dy already carries the activation's derivative."""
     check(lib.cvg_bn_act_bwd(ptr(dy), ptr(y), ptr(x), ptr(dx), dt(x), M, C_, ptr(stats), ptr(gamma), ptr(beta),
                              ptr(dgamma), ptr(dbeta), ptr(ws), stream()))
 

@@ -84,9 +84,12 @@ int    cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* 
  * dtype, N, B, OH, OW; each with its own taps, packed weights and output offsets): the four
  * output-parity classes of the input gradient of the stride-2 convolutions
  * (ConvResBlock's conv3x3 stride 2, networks.py:198-221).  No bias / residual epilogue.
- * descs points to n consecutive descriptors, w to n packed-weight pointers.               */
+ * descs points to n consecutive descriptors, w to n packed-weight pointers.
+ * gate (optional, laid out as y): y = conv * (gate > 0 ? 1 : 0.2), the derivative of the
+ * LeakyReLU in front of the stride-2 convolution (networks.py:220), so that y is the gradient
+ * of the res block's pre-activation sum and no consumer has to read gate again.          */
 int cvg_conv_fwd_group(int32_t n, const cvg_conv_desc* descs, const void* x,
-                       const void* const* w, void* y, cvg_stream s);
+                       const void* const* w, void* y, const void* gate, cvg_stream s);
 
 /* Weight gradient:  dWg[n][k] = sum_m dY[m][n] * gather(x)[m][k], then scattered to
  * the canonical (reference-layout) f32 gradient through `map`.
@@ -204,7 +207,8 @@ int cvg_conv_bn_act_fwd(const cvg_conv_desc* d, const void* x, const void* w, vo
  * through cvg_conv_fwd's res/gate arguments.  ws as for cvg_bn_stats.
  * y may be NULL for a BatchNorm without a residual input: the sign of the activation is then
  * recomputed from x (gamma * xhat + beta, the expression cvg_bn_act_fwd evaluates), which
- * saves one of the three tensor reads of both passes; beta is only read in that case.   */
+ * saves one of the three tensor reads of both passes; beta is only read in that case.
+ * y = NULL and beta = NULL: dy already carries the activation's derivative (g = dy).     */
 int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32_t dtype,
                    int32_t M, int32_t C, const float* stats, const float* gamma, const float* beta,
                    float* dgamma, float* dbeta, float* ws, cvg_stream s);

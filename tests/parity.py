@@ -66,6 +66,9 @@ def oracle_pass(case, step=0, state=None):
         t.retain_grad()
     vae.backward()
     agrads = OrderedDict((k, t.grad) for k, t in acts.items() if t.grad is not None)
+    for k in list(agrads):
+        if k.endswith(".r"):       # the engine keeps the gradient of the pre-activation sum: r.grad * LeakyReLU'(r)
+            agrads[k] = agrads[k] * torch.where(acts[k] > 0, 1.0, O.LRELU_SLOPE).to(agrads[k].dtype)
     pgrads = OrderedDict((k, p.grad) for k, p in params.items())
     return dict(acts=acts, agrads=agrads, pgrads=pgrads, losses=dict(VAE=vae, KL=kl, LL=ll),
                 z_mean=mu, z_sigma=sigma, new_stats=new_stats)
