@@ -30,6 +30,7 @@ struct PatchWgradPlan {
     int ok;
     int BNW, WN, WT;             // output channels per workgroup, waves over n, waves over taps
     int nine;                    // 1: the nine-tap double-buffered kernel (WT then counts chunks per workgroup)
+    int stride;                  // 1, or 2 (nine-tap kernel only)
     int TB, TH, TW, PH, PW, KH, KW, T;
     int tiles_y, tiles_x, groups, ntiles, nsplit, tiles_per_split;
     int patch_px, nchunks, n_tiles;

@@ -741,7 +741,10 @@ __device__ __forceinline__ bf16x8 tr_read2(const char* base, int o0, int o1) {
     return r;
 }
 
-template <int WN, int WC>
+// S: stride of the convolution (1 or 2).  With S = 2 the patch of a tile is (2 TH + 1) x (2 TW + 1)
+// pixels per image, 4.5 x the tile instead of 1.4 x, but still one staging for all nine taps
+// (the gather kernel fetches every tap's operand separately).
+template <int WN, int WC, int S = 1>
 __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgradArgs a) {
     typedef bf16 T;
     constexpr int ES = 2, TAPS = 9;
@@ -753,7 +756,8 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
     constexpr int NT = 64 * WN * WC;                           // threads: 4 waves, or 8 (two per SIMD)
     constexpr bool LEAN = NT == 512;                           // 256 registers per wave: no second fragment set
     constexpr int GPR = GW / 16, GIT = TPX * GPR / NT;         // dY pieces per row / per thread
-    constexpr int NIT = 256 * CPP * WC / NT;                   // patch pieces per thread (patch_px <= 256)
+    constexpr int MAXP = S == 1 ? 256 : 592;                   // patch pixels per chunk the staging registers cover
+    constexpr int NIT = (MAXP * CPP * WC + NT - 1) / NT;       // patch pieces per thread
     static_assert(NT == 256 || NT == 512, "4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -819,7 +823,7 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
         const int r = tl - grp * a.tiles_per_group;
         const int tile_y = fdiv(r, t.div_tx), tile_x = r - tile_y * t.tiles_x;
         const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = grp * t.TB;
-        const int iy0 = y0 + a.off_y, ix0 = x0 + a.off_x;
+        const int iy0 = y0 * S + a.off_y, ix0 = x0 * S + a.off_x;
         const T* xt = xp + ((ptrdiff_t)b0 * a.x_img_pitch + (ptrdiff_t)iy0 * a.x_row_pitch + (ptrdiff_t)ix0 * a.x_pix_pitch);
         const T* gt = gp + ((ptrdiff_t)b0 * a.dy_img_pitch + (ptrdiff_t)y0 * a.dy_row_pitch + (ptrdiff_t)x0 * a.dy_pix_pitch);
 #pragma unroll
@@ -878,7 +882,7 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
             const int qq = s_ * 16 + 8 * h + lq + 4 * e;
             int tb, ty, tx;
             tile_px(t, qq < t.npx ? qq : 0, tb, ty, tx);
-            pr[e] = wc * chunk_stride + ((tb * t.PH + ty) * t.PW + tx) * PP + cofs;
+            pr[e] = wc * chunk_stride + ((tb * t.PH + ty * S) * t.PW + tx * S) * PP + cofs;
             gr[e] = patch_bytes + qq * PG + wn * 64 + cofs;
         }
     };
@@ -938,8 +942,8 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
 }
 
 // ---- host side -----------------------------------------------------------------------------
-void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x) {
-    t.TB = TB; t.TH = TH; t.TW = TW; t.PH = TH + KH - 1; t.PW = TW + KW - 1;
+void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x, int S = 1) {
+    t.TB = TB; t.TH = TH; t.TW = TW; t.PH = (TH - 1) * S + KH; t.PW = (TW - 1) * S + KW;
     t.npx = TB * TH * TW; t.tiles_x = tiles_x;
     t.div_tw = make_fastdiv(TW); t.div_thw = make_fastdiv(TH * TW);
     t.div_pw = make_fastdiv(t.PW); t.div_phw = make_fastdiv(t.PH * t.PW);
@@ -957,11 +961,11 @@ bool patch_eligible(const cvg_conv_desc* d) {
 }
 
 // Smallest number of tiles, then the smallest patch, over all TH x TW <= BM.
-bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int& TB, int& TH, int& TW) {
+bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int& TB, int& TH, int& TW, int S = 1) {
     long best_tiles = -1, best_patch = 0;
     for (int th = 1; th <= OH && th <= BM; ++th)
         for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
-            const int pp = (th + KH - 1) * (tw + KW - 1);
+            const int pp = ((th - 1) * S + KH) * ((tw - 1) * S + KW);
             int tb = BM / (th * tw);
             if (tb > B) tb = B;
             if (tb > max_patch_px / pp) tb = max_patch_px / pp;
@@ -1156,6 +1160,30 @@ int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap
 
 void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     p.ok = 0;
+    p.stride = 1;
+    static const bool no_s2 = getenv("CVG_WGRAD_S2_GATHER") != nullptr;      // A/B switch for benchmarking
+    if (!no_s2 && d->stride == 2 && d->tstep_y == 1 && d->tstep_x == 1 && d->dtype == CVG_BF16 && d->KW == 3 &&
+        d->ntaps == 9 && d->N > 64 && d->Cin % CK == 0 && d->x_pix_pitch == d->Cin && d->pad_mode == CVG_PAD_ZERO &&
+        (int64_t)d->B * d->x_img_pitch < (1ll << 31) && (int64_t)d->B * d->y_img_pitch < (1ll << 31) &&
+        choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 592, p.TB, p.TH, p.TW, 2)) {
+        // the nine-tap kernel, four waves, one 32-channel chunk per workgroup
+        p.KW = 3; p.KH = 3; p.T = 9; p.WN = 4; p.WT = 1; p.BNW = 128;
+        p.PH = 2 * p.TH + 1; p.PW = 2 * p.TW + 1;
+        p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
+        p.ntiles = p.tiles_y * p.tiles_x * p.groups;
+        p.patch_px = p.TB * p.PH * p.PW;
+        p.nchunks = d->Cin / CK;
+        p.n_tiles = ceil_div(d->N, p.BNW);
+        const double eff = (double)d->B * d->OH * d->OW / ((double)p.ntiles * 128);
+        int want = ceil_div(256, p.nchunks * p.n_tiles);
+        if (want > p.ntiles) want = p.ntiles;
+        if (want < 1) want = 1;
+        p.tiles_per_split = ceil_div(p.ntiles, want);
+        p.nsplit = ceil_div(p.ntiles, p.tiles_per_split);
+        p.lds_bytes = 2 * ((size_t)((p.patch_px * CK * 2 + 255) & ~255) + (size_t)128 * (128 * 2 + 64));
+        p.ws_bytes = (size_t)p.nsplit * (p.n_tiles * p.BNW) * ((size_t)p.T * d->Cin) * sizeof(float);
+        if (eff >= 0.5 && p.lds_bytes <= 160 * 1024) { p.nine = 1; p.stride = 2; p.ok = 1; return; }
+    }
     if (!patch_eligible(d)) return;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
@@ -1237,7 +1265,7 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     a.patch_px = p.patch_px; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     a.tiles_per_group = p.tiles_y * p.tiles_x;
     a.n_rows = p.n_tiles * p.BNW; a.k_ld = p.T * d->Cin;
-    fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
+    fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x, p.stride);
     a.div_tpg = make_fastdiv(a.tiles_per_group);
     const int tpw = p.T == 7 ? (p.WN == 1 ? 3 : 5) : ceil_div(p.T, p.WT);
     int rc = -1;
@@ -1249,7 +1277,10 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
         b.xcd_remap = no_remap ? 0 : 1;
         const int64_t nwg = (int64_t)b.nchunks_ntiles * p.nsplit;
         if (nwg >= (1ll << 31)) CVG_FAIL("patch_wgrad: too many workgroups");
-        if (p.WT == 1) {
+        if (p.stride == 2) {
+            if (set_lds(patch_wgrad9<4, 1, 2>, p.lds_bytes)) return -1;
+            patch_wgrad9<4, 1, 2><<<(int)nwg, 256, p.lds_bytes, s>>>(b);
+        } else if (p.WT == 1) {
             if (set_lds(patch_wgrad9<4, 1>, p.lds_bytes)) return -1;
             patch_wgrad9<4, 1><<<(int)nwg, 256, p.lds_bytes, s>>>(b);
         } else if (p.WN == 4) {
