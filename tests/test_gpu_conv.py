@@ -44,7 +44,7 @@ def ws_for(ops, desc):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,cin,cout,stride", [(3, 12, 16, 24, 1), (3, 12, 16, 32, 1), (2, 16, 64, 64, 1),
                                                  (1, 8, 128, 256, 1), (3, 12, 16, 40, 2), (3, 12, 8, 16, 2),
-                                                 (2, 16, 64, 128, 2)])
+                                                 (2, 16, 64, 128, 2), (3, 40, 32, 128, 2)])
 def test_conv3x3_fwd_dgrad_wgrad(dtype, B, H, cin, cout, stride):
     ops, _desc, _wmap = _mods()
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + cin + stride)
