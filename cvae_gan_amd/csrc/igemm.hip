@@ -203,6 +203,31 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
     constexpr int ES = (int)sizeof(T);
     constexpr int OP = BN * ES + 16;             // staged row pitch
     static_assert(BM * OP == OUT_BYTES, "staged tile size");
+    constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
+    constexpr int EPP = 16 / ES;
+    constexpr int NPC = BM * PPR / 256;          // pieces per thread in the second half
+    // output gating (y = conv * LeakyReLU'(gate)): the gate pieces this thread will need in the second
+    // half are requested now, so that they arrive while the accumulators go through LDS
+    const bool gate_only = gatep && !resp;
+    u32x4 gq[NPC];
+    if (gate_only) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int idx = tid + 256 * i;
+            const int ml = idx / PPR, pc = idx % PPR;
+            const int m = m0 + ml, n = n0 + pc * EPP;
+            gq[i] = u32x4{0u, 0u, 0u, 0u};
+            if (m >= g.M || n >= a.N) continue;
+            const uint32_t b = fdiv(m, g.div_ohw);
+            const uint32_t rem = m - b * g.OHW;
+            const uint32_t oy = fdiv(rem, g.div_ow);
+            const uint32_t ox = rem - oy * g.OW;
+            const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
+                                (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+            if (n + EPP <= a.N) gq[i] = *(const u32x4*)(gatep + yoff + n);
+            else { const unsigned long long g8 = *(const unsigned long long*)(gatep + yoff + n); gq[i][0] = (unsigned)g8; gq[i][1] = (unsigned)(g8 >> 32); }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int ml = wm * WTM + mi * 32 + l31, m = m0 + ml;
@@ -257,10 +282,8 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
     }
     if (a.ksplit > 1) return;                    // uniform over the grid
     __syncthreads();
-    constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
-    constexpr int EPP = 16 / ES;
 #pragma unroll
-    for (int i = 0; i < BM * PPR / 256; ++i) {
+    for (int i = 0; i < NPC; ++i) {
         const int idx = tid + 256 * i;
         const int ml = idx / PPR, pc = idx % PPR;
         const int m = m0 + ml, n = n0 + pc * EPP;
@@ -272,12 +295,7 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
         const size_t yoff = (size_t)b * a.y_img_pitch + (size_t)(oy * a.oy_mul + a.oy_off) * a.y_row_pitch +
                             (size_t)(ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
         u32x4 v = *(const u32x4*)(smem + ml * OP + pc * 16);
-        if (gatep && !resp) {                    // output gating: y = conv * LeakyReLU'(gate)
-            u32x4 gq = {0u, 0u, 0u, 0u};
-            if (n + EPP <= a.N) gq = *(const u32x4*)(gatep + yoff + n);
-            else { const unsigned long long g8 = *(const unsigned long long*)(gatep + yoff + n); gq[0] = (unsigned)g8; gq[1] = (unsigned)(g8 >> 32); }
-            v = mul_gate<T>(v, gq);
-        }
+        if (gate_only) v = mul_gate<T>(v, gq[i]);
         if (n + EPP <= a.N) {
             *(u32x4*)(yp + yoff + n) = v;
         } else {                                 // N is a multiple of 4: half a 16-bit piece
