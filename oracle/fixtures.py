@@ -1,4 +1,4 @@
-"""Helpers shared by tools/gen_goldens.py and the tests (TEST INFRASTRUCTURE ONLY).
+"""Helpers shared by tests/golden/gen_goldens.py and the tests (TEST INFRASTRUCTURE ONLY).
 
 Large tensors (parameter gradients, updated weights at ngf=64) are kept in the
 fixtures in a compact form so that the committed files stay small: a strided

@@ -6,7 +6,7 @@ It is the checker the HIP path is compared against; it is never the thing that i
 shipped or measured as the product.  Only tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg may import it.
 
-Parity status: PINNED.  tools/gen_goldens.py imports the reference's own network
+Parity status: PINNED.  tests/golden/gen_goldens.py imports the reference's own network
 classes (models/networks.py) on the CPU, runs them on seeded inputs and writes the
 fixtures under tests/golden/; tests/test_oracle_golden.py checks every function
 here against those fixtures.

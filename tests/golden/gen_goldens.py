@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/*.npz from the reference's own network classes.
+"""Generate the *.npz fixtures in this directory from the reference's own network classes.
 
 Runs in the build container only (it needs /root/reference); the GPU box and the
 test-suite read the committed fixtures, never the reference.  The reference's
@@ -23,12 +23,12 @@ os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import ref_cpu as O          # noqa: E402
 from oracle.fixtures import put          # noqa: E402
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def _stub_modules():

@@ -1,5 +1,5 @@
 """The CPU oracle must reproduce the fixtures recorded from the reference's own
-network classes (tools/gen_goldens.py).  fp32 against fp32 on the same CPU kernels,
+network classes (tests/golden/gen_goldens.py).  fp32 against fp32 on the same CPU kernels,
 so tolerances are tight; they are not bit-exact only because the oracle's
 BatchNorm is written out by hand and autograd orders a few sums differently."""
 import numpy as np
