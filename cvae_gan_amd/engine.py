@@ -639,6 +639,10 @@ class Engine:
     def enc_forward(self, x, labels):
         """x: f32 NCHW [B,3,P,P] on the device; labels: int32 [B].  Returns h [B, 2z]."""
         e, B, P, ngf = self.enc, self.B, self.P, self.ngf
+        if self.training and B == 1:
+            # what nn.BatchNorm1d (models/networks.py:188) raises in train mode for one sample
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             "torch.Size([1, %d])" % e["fcd"])
         self.pack_weights()
         if self.y > 0:
             e["labels"].copy_(labels)

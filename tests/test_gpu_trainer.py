@@ -41,6 +41,23 @@ def test_eval_forward_matches_reference(name):
     assert ok, msg
 
 
+def test_single_image_batch():
+    """One sample: train mode raises what nn.BatchNorm1d raises (models/networks.py:188); eval mode
+    (running statistics) gives the same row as the fixture's batch does."""
+    from cvae_gan_amd.engine import Engine
+    c = Case("tiny_p16_ngf8")
+    st = _after3_state(c)
+    x, labels, _, _ = c.inputs(c.n_steps - 1)
+    eps = torch.from_numpy(c.npz["eval/eps"])
+    eng = Engine(c.P, c.y, c.z, 1, dtype=torch.float32, ngf=c.ngf, state=st)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        eng.forward_backward(x[:1].cuda(), labels[:1].int().cuda(), eps[:1].cuda(), 1.0)
+    eng.training = False
+    out = eng.reconstruct(x[:1].cuda(), labels[:1].int().cuda(), eps[:1].cuda()).cpu().numpy()
+    ref = c.npz["eval/full"][:1]
+    assert np.abs(out - ref).max() <= 1e-3 * np.abs(ref).max(), np.abs(out - ref).max()
+
+
 class Args:
     pass
 
