@@ -141,7 +141,7 @@ class CVAE(object):
     def batches(self):
         """(x f32 NCHW in [-1, 1], class indices int32), both on the device."""
         if self.device_preprocess:
-            return DevicePrefetcher(self.trainset_loader, self.batch_size, self.pix_dim, self.device)
+            return DevicePrefetcher(self.trainset_loader, self.batch_size, self.pix_dim, self.device, y_dim=self.y_dim)
         return (self._to_device(imgs, labels) for imgs, labels in self.trainset_loader)
 
     def train(self):

@@ -91,9 +91,10 @@ class DevicePrefetcher:
     (cvg_image_u8_to_f32).  Yields (x f32 NCHW in [-1, 1], labels int32), both on the device and
     valid until the next-but-one batch is requested (two buffer sets)."""
 
-    def __init__(self, loader, batch_size, pix_dim, device):
+    def __init__(self, loader, batch_size, pix_dim, device, y_dim=None):
         from . import ops
         self.loader, self.ops, self.B, self.P = loader, ops, batch_size, pix_dim
+        self.y_dim = y_dim                                # class count, to reject labels the one-hot cannot hold
         self.device = torch.device(device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.sets = []
@@ -115,6 +116,10 @@ class DevicePrefetcher:
         s["consumed"].synchronize()                       # the consumer's kernels on this set have run
         s["h_img"].copy_(imgs)
         s["h_lab"].copy_(torch.as_tensor(labels).to(torch.int32))
+        if self.y_dim is not None:
+            lo, hi = int(s["h_lab"].min()), int(s["h_lab"].max())
+            if lo < 0 or hi >= self.y_dim:                # the reference fails indexing its one-hot table (models/cvae.py:129)
+                raise IndexError("label %d is out of bounds for y_dim %d" % (hi if hi >= self.y_dim else lo, self.y_dim))
         with torch.cuda.stream(self.copy_stream):
             s["d_img"].copy_(s["h_img"], non_blocking=True)
             s["d_lab"].copy_(s["h_lab"], non_blocking=True)

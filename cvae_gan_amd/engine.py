@@ -645,7 +645,11 @@ class Engine:
                              "torch.Size([1, %d])" % e["fcd"])
         self.pack_weights()
         if self.y > 0:
+            # class indices address the per-class bias table, its gradient rows and the one-hot
+            # columns of the decoder input: kept inside [0, y) so that a bad index cannot leave
+            # those buffers (validation with an error is the data path's job, it sees host labels)
             e["labels"].copy_(labels)
+            e["labels"].clamp_(0, self.y - 1)
         ops.pack_image(x, e["xpad"], B, P)
         self._conv_bn(e["stem"], e["xpad"], e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2",
                       bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],

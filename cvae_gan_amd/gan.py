@@ -97,7 +97,7 @@ class CVAEGAN:
         self.x3[:B].copy_(x)
         self.x3[B:2 * B].copy_(dec_f)
         self.x3[2 * B:].copy_(dec_p)
-        self.labels_dev[:B].copy_(labels)
+        self.labels_dev[:B].copy_(A.enc["labels"])        # the copy enc_forward made: inside [0, y)
         # ---- critics: own losses (parameter gradients), then the matching losses (image gradients)
         M, F = 3 * B, D.F
         hD = D.forward(self.x3)

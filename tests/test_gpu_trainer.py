@@ -58,6 +58,27 @@ def test_single_image_batch():
     assert np.abs(out - ref).max() <= 1e-3 * np.abs(ref).max(), np.abs(out - ref).max()
 
 
+def test_label_out_of_range():
+    """The data path rejects a class index the one-hot cannot hold (IndexError, as the reference's
+    table lookup at models/cvae.py:129); the engine itself keeps indices inside its tables."""
+    from cvae_gan_amd.datasets import DevicePrefetcher
+    from cvae_gan_amd.engine import Engine
+    imgs = torch.zeros(4, 16, 16, 3, dtype=torch.uint8)
+    loader = [(imgs, torch.tensor([0, 1, 7, 2]))]
+    with pytest.raises(IndexError, match="out of bounds"):
+        list(DevicePrefetcher(loader, 4, 16, "cuda", y_dim=4))
+    assert len(list(DevicePrefetcher(loader, 4, 16, "cuda", y_dim=8))) == 1
+    eng = Engine(16, 4, 8, 4, dtype=torch.float32, ngf=8, seed=0)
+    x = torch.rand(4, 3, 16, 16, device="cuda") * 2 - 1
+    eps = torch.randn(4, 8, device="cuda")
+    eng.random_mask(seed=1)
+    eng.forward_backward(x, torch.tensor([0, 1, 7, -3], dtype=torch.int32, device="cuda"), eps, 4.0)
+    a = eng.read_losses()
+    eng.random_mask(seed=1)
+    eng.forward_backward(x, torch.tensor([0, 1, 3, 0], dtype=torch.int32, device="cuda"), eps, 4.0)
+    assert eng.read_losses() == a                         # 7 -> 3, -3 -> 0
+
+
 class Args:
     pass
 
