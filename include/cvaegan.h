@@ -68,7 +68,9 @@ typedef struct cvg_conv_desc {
  *   w      weights [w_rows][w_ld] (dtype), row n = output channel, zero padded
  *   y      output (dtype)
  *   bias   f32 [N] or NULL
- *   cbias  f32 [n_class][N] per-class bias or NULL; labels int32 [B]
+ *   cbias  f32 [n_class][N] per-class bias or NULL; labels int32 [B], every entry in
+ *          [0, n_class): the kernels index tables with them unchecked (here and in
+ *          cvg_label_bias_bwd, cvg_reparam_kl_fwd, cvg_gan_c_head); the caller validates
  *          (the encoder's one-hot label planes folded into the stem)
  *   res    tensor added to the output, addressed like y, or NULL
  *   gate   if non-NULL, res is scaled by (gate > 0 ? 1 : 0.2) elementwise
