@@ -572,7 +572,7 @@ int fwd_ksplit(const cvg_conv_desc* d, int M, bool dense) {
     const int nk = ceil_div((int64_t)d->ntaps * d->Cin, BK);
     const int tiles = ceil_div(M, 128) * ceil_div(d->N, 128);
     if (!dense || tiles >= 192 || nk < 16) return 1;
-    int ks = 256 / tiles;
+    int ks = 512 / tiles;                        // two workgroups fit a CU
     if (ks > nk / 4) ks = nk / 4;
     if (ks > 64) ks = 64;
     return ks < 1 ? 1 : ks;
