@@ -979,13 +979,19 @@ bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px
     return best_tiles > 0;
 }
 
+// Dynamic LDS beyond 64 KB has to be granted per kernel and per device; the grant is remembered per
+// kernel instantiation and device (a benign race: two threads may both set the same attribute).
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-    static size_t granted = 64 * 1024;           // per kernel instantiation
-    if (bytes > granted) {
-        granted = bytes;
+    constexpr int MAX_DEV = 64;
+    static size_t granted[MAX_DEV];
+    if (bytes <= 64 * 1024) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) CVG_FAIL("set_lds: no current device");
+    if (bytes > granted[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) CVG_FAIL("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+        granted[dev] = bytes;
     }
     return 0;
 }
