@@ -225,7 +225,8 @@ def test_tail_forward_through_column_partials(dtype, B, P, ngf):
 def test_batchnorm_leakyrelu_forward_backward(dtype, M, C, with_res):
     """cvg_bn_stats + cvg_bn_act_fwd + cvg_bn_act_bwd against torch autograd on the CPU.
     Without a residual input the backward is run twice: with the gate read from y and with the
-    gate recomputed from x (y = NULL); the two must agree bit for bit."""
+    gate recomputed from x (y = NULL); the two must agree bit for bit.  A third run hands over dy
+    already gated (y = NULL, beta = NULL)."""
     ops, _, _ = _mods()
     g = torch.Generator().manual_seed(M + C)
     x = torch.randn(M, C, generator=g) * 1.5 + 0.3
@@ -267,4 +268,19 @@ def test_batchnorm_leakyrelu_forward_backward(dtype, M, C, with_res):
         assert relmax(dxd.float().cpu(), xr.grad) <= max(tol, 1e-4)
     if not with_res and dtype == torch.float32:
         for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    # third form: the caller hands over dy already multiplied by the activation's derivative
+    # (y = NULL and no beta); in f32 it must equal the gated-from-y result bit for bit
+    gated = dy * torch.where(yr.detach() > 0, 1.0, 0.2)
+    if dtype == torch.bfloat16:
+        gated = gated.bfloat16().float()
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dxd.zero_()
+    ops.bn_act_bwd(dev(gated), None, xd, dxd, M, C, stats, gd, dg, db, ws, beta=None)
+    torch.cuda.synchronize()
+    assert relmax(dg.cpu(), gr.grad) <= max(tol, 1e-4)
+    assert relmax(db.cpu(), br.grad) <= max(tol, 1e-4)
+    assert relmax(dxd.float().cpu(), xr.grad) <= max(tol, 1e-4)
+    if dtype == torch.float32:
+        for a, b in zip((dxd, dg, db), outs[0]):
             assert torch.equal(a, b)
