@@ -681,9 +681,10 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
     hipStream_t s = (hipStream_t)stream;
     const bool gate_only = gate && !res;         // y = conv * LeakyReLU'(gate): gather kernel, no split-K
-    if (patch_enabled() && !gate_only) {
+    if (patch_enabled()) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
+        CVG_CHECK(!(pp.ok && gate_only), "conv_fwd: gate without res is implemented by the gather kernel only; this layer's weights are packed for the patch kernel");
         if (pp.ok) return patch_fwd_launch(d, pp, x, w, y, bias, cbias, labels, res, gate, s);
     }
     a.nk_total = ceil_div(a.g.Kvalid, BK);

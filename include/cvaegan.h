@@ -74,7 +74,9 @@ typedef struct cvg_conv_desc {
  *          (the encoder's one-hot label planes folded into the stem)
  *   res    tensor added to the output, addressed like y, or NULL
  *   gate   if non-NULL, res is scaled by (gate > 0 ? 1 : 0.2) elementwise
- *          (LeakyReLU derivative read from the saved activation)
+ *          (LeakyReLU derivative read from the saved activation); without res the
+ *          OUTPUT is scaled instead (layers on the gather kernel only, see
+ *          cvg_conv_fwd_kernel(); a bias is added before the scaling, split-K is off)
  *   ws     f32 workspace of cvg_conv_fwd_workspace() bytes (split-K partials)    */
 size_t cvg_conv_fwd_workspace(const cvg_conv_desc* d);
 int    cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y,

@@ -120,6 +120,34 @@ def test_conv_bias_residual_gate(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_output_gate(dtype):
+    """gate without res: the output is multiplied by the LeakyReLU derivative of `gate` (gather
+    kernel, here a stride-2 conv); a layer whose weights are packed for the patch kernel refuses it."""
+    ops, _desc, _wmap = _mods()
+    g = torch.Generator().manual_seed(6)
+    B, H, cin, cout = 3, 12, 16, 40
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 12
+    gate = torch.randn(B, cout, H // 2, H // 2, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, gate = [t.bfloat16().float() for t in (x, w, gate)]
+    ref = F.conv2d(x, w, None, 2, 1) * torch.where(gate > 0, 1.0, 0.2)
+    d = _desc(dtype, B, H, H, cin, H // 2, H // 2, cout, 3, 9, stride=2, off=(-1, -1))
+    wm = _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9)
+    yr = torch.zeros(B * (H // 2) ** 2, cout, dtype=dtype, device="cuda")
+    ops.conv_fwd(d, to_rows(x, dtype), pack(ops, wm, w, d, dtype), yr, gate=to_rows(gate, dtype), ws=ws_for(ops, d))
+    assert relmax(from_rows(yr, B, H // 2, H // 2, cout), ref) < TOL[dtype]
+    d1 = _desc(dtype, 2, 8, 8, 32, 8, 8, 64, 3, 9, off=(-1, -1))          # stride 1, 32 channels: patch kernel
+    if ops.conv_fwd_kernel(d1).startswith("patch_fwd"):
+        wm1 = _wmap(1, 32 * 9, 0, 32, 1, 9, 64, 32, 9)
+        w1 = torch.randn(64, 32, 3, 3, generator=g)
+        y1 = torch.zeros(2 * 64, 64, dtype=dtype, device="cuda")
+        x1 = torch.zeros(2 * 64, 32, dtype=dtype, device="cuda")
+        with pytest.raises(RuntimeError, match="gather kernel only"):
+            ops.conv_fwd(d1, x1, pack(ops, wm1, w1, d1, dtype), y1, gate=y1, ws=ws_for(ops, d1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_reflect_7x7_to3(dtype):
     """Decoder tail: ReflectionPad2d(3) + Conv2d(C, 3, 7) with 3 of 4 stored channels valid."""
     ops, _desc, _wmap = _mods()
