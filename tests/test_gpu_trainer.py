@@ -189,3 +189,27 @@ def test_starter_command_line(tmp_path):
     assert "Training finish" in r.stdout
     d = os.path.join(str(tmp_path / "ck"), "VAE_data_Synth_pix_32_batch_16_embed_8")
     assert os.path.exists(os.path.join(d, "Synth_encoder.pkl")) and os.path.exists(os.path.join(d, "Synth_decoder.pkl"))
+
+
+def test_bench_prints_one_json_line():
+    """bench.py's contract: stdout is exactly one JSON line with the metric, the roofline of the
+    dominant kernel and (single GPU) the CPU baseline fields; everything else goes to stderr."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "bench.py", "--config", "c2", "--batch", "32", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert all(v == v and abs(v) < 1e6 for v in d["losses_last_step"].values())      # finite
