@@ -130,7 +130,7 @@ class KernelTimer:
         agg = {}
         for name, fl, a, b, g in self.records:
             d = g.desc
-            key = (g.key.replace("encoder.module.", "E.").replace("decoder.module.", "D."), name,
+            key = (g.key.replace("encoder.", "E.").replace("decoder.", "D."), name,
                    d.B * d.OH * d.OW, d.N, d.ntaps * d.Cin, d.stride, d.oy_off * 2 + d.ox_off, id(g))
             s = agg.setdefault(key, [fl, 0.0])
             s[1] += a.elapsed_time(b) * 1e-3 / reps

@@ -1,7 +1,8 @@
 """The CVAE train-step executor for MI355X.
 
 Engine owns the canonical parameters (f32, reference layouts and checkpoint keys,
-models/cvae.py:234-235), their gradient / AdamW-moment arenas, the packed weight
+models/cvae.py:234-235:
+"encoder.conv.1.weight", ...), their gradient / AdamW-moment arenas, the packed weight
 shadows and every activation buffer, and drives the HIP kernels stage by stage:
 
     enc_forward -> sample -> dec_forward -> [loss] -> dec_backward ->
@@ -28,8 +29,12 @@ import torch
 from . import ops
 from ._lib import ConvDesc, WMap, PAD_ZERO, PAD_REFLECT
 
-EP = "encoder.module."
-DP = "decoder.module."
+# Checkpoint key prefixes.  The reference saves self.En.module.state_dict() (models/cvae.py:234-235):
+# En.module is the `encoder` wrapper, whose one child attribute is `self.encoder` (the inner
+# ResNetEncoder; the nn.DataParallel that init_net builds around it is dropped, models/networks.py:82-83),
+# so the keys read "encoder.conv.1.weight", "decoder.conv.0.2.weight", ...
+EP = "encoder."
+DP = "decoder."
 ADAM_BETAS = (0.5, 0.999)        # models/cvae.py:67
 ADAM_EPS = 1e-8
 ADAM_WD = 1e-2                   # torch.optim.AdamW default
@@ -104,15 +109,31 @@ def is_buffer(key):
 
 
 def init_state(P, y_dim, z_dim, seed=0, n_stage=4, ngf=64):
-    """init_weights(net, 'kaiming') semantics (models/networks.py:283-304): conv and
-    linear weights kaiming_normal_(a=0, fan_in), biases 0, BatchNorm2d gamma ~ N(1,.02),
-    BatchNorm1d untouched (gamma 1).  Host-side, once; returns CPU tensors."""
+    """The parameters torch.manual_seed(seed); encoder(args); decoder(args) leaves behind
+    (models/cvae.py:57-58), bit for bit.  Host-side, once; returns CPU tensors.
+
+    Each wrapper first constructs its network, whose nn.Conv2d / nn.Linear constructors draw
+    their default initialisation (weight kaiming_uniform_(a=sqrt 5), then the bias uniform in
+    +-1/sqrt(fan_in)) in definition order, and then runs init_weights(net, 'kaiming')
+    (models/networks.py:283-304), which walks the modules in the same order and draws conv and
+    linear weights kaiming_normal_(a=0, fan_in), sets their biases to 0, draws BatchNorm2d gamma
+    ~ N(1, 0.02) and leaves BatchNorm1d alone (gamma 1: the class-name test at :299 only matches
+    'BatchNorm2d').  The first round of draws is overwritten but moves the generator, so it is
+    replayed here on scratch tensors."""
+    from torch.nn import init
     g = torch.Generator().manual_seed(seed)
     enc_s, dec_s = param_shapes(P, y_dim, z_dim, n_stage, ngf)
     out = []
     for shapes in (enc_s, dec_s):
+        for k, shp in shapes.items():               # constructors (models/networks.py:164-191, :129-157)
+            if len(shp) < 2:
+                continue
+            init.kaiming_uniform_(torch.empty(shp), a=math.sqrt(5), generator=g)
+            if k[:-len("weight")] + "bias" in shapes:
+                bound = 1.0 / math.sqrt(int(torch.Size(shp[1:]).numel()))
+                init.uniform_(torch.empty(shp[0]), -bound, bound, generator=g)
         sd = OrderedDict()
-        for k, shp in shapes.items():
+        for k, shp in shapes.items():               # init_weights' net.apply(init_func)
             if k.endswith("num_batches_tracked"):
                 sd[k] = torch.zeros((), dtype=torch.long)
             elif k.endswith("running_mean"):
@@ -120,14 +141,13 @@ def init_state(P, y_dim, z_dim, seed=0, n_stage=4, ngf=64):
             elif k.endswith("running_var"):
                 sd[k] = torch.ones(shp)
             elif len(shp) >= 2:
-                fan_in = 1
-                for s_ in shp[1:]:
-                    fan_in *= s_
-                sd[k] = torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_in)
+                sd[k] = init.kaiming_normal_(torch.empty(shp), a=0, mode="fan_in", generator=g)
             elif k.endswith(".bias"):
                 sd[k] = torch.zeros(shp)
+            elif ".fc.1." in k:
+                sd[k] = torch.ones(shp)
             else:
-                sd[k] = torch.ones(shp) if ".fc.1." in k else 1.0 + 0.02 * torch.randn(shp, generator=g)
+                sd[k] = init.normal_(torch.empty(shp), 1.0, 0.02, generator=g)
         out.append(sd)
     return out[0], out[1]
 
@@ -321,6 +341,8 @@ class Engine:
         """Copy reference-layout tensors (either checkpoint's keys) into the engine."""
         with torch.no_grad():
             for k, v in state.items():
+                if k not in self.params and k not in self.buffers and ".module." in k:
+                    k = k.replace(".module.", ".", 1)       # an inner net saved with its nn.DataParallel level
                 if k in self.params:
                     assert tuple(v.shape) == tuple(self.shapes[k]), (k, tuple(v.shape), self.shapes[k])
                     self.params[k].copy_(v.to(torch.float32))

@@ -3,7 +3,7 @@
     encoder(args), decoder(args), CVAE_T(args, encoder, decoder), latent_loss(...)
 
 keep the reference's constructor arguments, call signatures, attributes (z_mean, z_sigma)
-and checkpoint keys ("encoder.module.conv.1.weight", ...), so the training loop of
+and checkpoint keys ("encoder.conv.1.weight", ...), so the training loop of
 models/cvae.py:125-157 runs on them unchanged: forward, torch losses on the outputs,
 loss.backward(), torch.optim.AdamW.step().  Parameters are ordinary nn.Parameters whose
 storage is the engine's canonical f32 arena.

@@ -14,8 +14,8 @@ here against those fixtures.
 All tensors use the reference's layouts: images NCHW, conv weights OIHW, linear
 weights [out, in].  Parameters travel in two dicts that use the reference's
 checkpoint keys (models/cvae.py:234-235):
-    encoder:  "encoder.module.conv.1.weight", ... "encoder.module.fc.3.bias"
-    decoder:  "decoder.module.conv.0.2.weight", ... "decoder.module.fc.3.bias"
+    encoder:  "encoder.conv.1.weight", ... "encoder.fc.3.bias"
+    decoder:  "decoder.conv.0.2.weight", ... "decoder.fc.3.bias"
 """
 import math
 from collections import OrderedDict
@@ -33,8 +33,8 @@ ADAM_BETAS = (0.5, 0.999)   # models/cvae.py:67
 ADAM_EPS = 1e-8
 ADAM_WD = 1e-2         # torch.optim.AdamW default, not overridden at models/cvae.py:67
 
-EP = "encoder.module."
-DP = "decoder.module."
+EP = "encoder."      # En.module.state_dict(): the wrapper's child attribute is `encoder` (networks.py:82)
+DP = "decoder."      # De.module.state_dict(): child attribute `decoder` (networks.py:60)
 
 
 # --------------------------------------------------------------------------- shapes
@@ -113,17 +113,27 @@ def is_buffer(key):
 
 def init_params(pix_dim, y_dim, z_dim, seed=0, dtype=torch.float32, n_stage=N_STAGE,
                 ngf=NGF):
-    """Fresh parameters drawn the way init_weights(net, 'kaiming') does
-    (models/networks.py:283-304): conv / linear weights kaiming_normal_(a=0,
-    fan_in), biases 0; BatchNorm2d gamma ~ N(1, 0.02), beta 0; BatchNorm1d left at
-    its constructor values (gamma 1, beta 0) because the class-name test at
-    models/networks.py:299 only matches 'BatchNorm2d'.  The draw ORDER differs
-    from the reference's module traversal, so seeds are not interchangeable;
-    goldens carry explicit initial weights instead."""
+    """The state torch.manual_seed(seed); encoder(args); decoder(args) produces
+    (models/cvae.py:57-58).  Each wrapper constructs its network (the nn.Conv2d and
+    nn.Linear constructors draw kaiming_uniform_(a=sqrt(5)) weights and uniform biases,
+    in definition order: models/networks.py:171-191, :139-157) and then calls
+    init_weights(net, 'kaiming') (models/networks.py:283-304): conv / linear weights
+    kaiming_normal_(a=0, fan_in), biases 0; BatchNorm2d gamma ~ N(1, 0.02), beta 0;
+    BatchNorm1d left at its constructor values (gamma 1, beta 0) because the class-name
+    test at models/networks.py:299 only matches 'BatchNorm2d'.  Module definition order,
+    net.apply() order and state_dict order coincide for both networks."""
+    torch_init = torch.nn.init
     g = torch.Generator().manual_seed(seed)
     enc_s, dec_s = param_shapes(pix_dim, y_dim, z_dim, n_stage, ngf)
     out = []
     for shapes in (enc_s, dec_s):
+        for k, shp in shapes.items():
+            if len(shp) >= 2:                       # constructor draws, overwritten below
+                w = torch.empty(shp)
+                torch_init.kaiming_uniform_(w, a=math.sqrt(5), generator=g)
+                if k.replace(".weight", ".bias") in shapes:
+                    fan_in = w[0].numel()
+                    torch.empty(shp[0]).uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in), generator=g)
         sd = OrderedDict()
         for k, shp in shapes.items():
             if k.endswith("num_batches_tracked"):
@@ -136,14 +146,14 @@ def init_params(pix_dim, y_dim, z_dim, seed=0, dtype=torch.float32, n_stage=N_ST
                 fan_in = 1
                 for s_ in shp[1:]:
                     fan_in *= s_
-                std = math.sqrt(2.0 / fan_in)
-                sd[k] = torch.randn(shp, generator=g, dtype=dtype) * std
+                std = math.sqrt(2.0) / math.sqrt(fan_in)
+                sd[k] = torch.empty(shp).normal_(0, std, generator=g).to(dtype)
             elif k.endswith(".bias"):
                 sd[k] = torch.zeros(shp, dtype=dtype)
             else:  # BatchNorm weight
                 is_bn1d = ".fc.1." in k
                 sd[k] = torch.ones(shp, dtype=dtype) if is_bn1d else \
-                    1.0 + 0.02 * torch.randn(shp, generator=g, dtype=dtype)
+                    torch.empty(shp).normal_(1.0, 0.02, generator=g).to(dtype)
         out.append(sd)
     return out[0], out[1]
 

@@ -85,23 +85,61 @@ class _Args:
     pass
 
 
+def wrappers_on_cpu(N):
+    """The reference's `encoder` / `decoder` wrapper classes call init_net(), which ends in
+    .to('cuda') (networks.py:309) and cannot run here.  Replace that one function, in the imported
+    module object only, by the same body without the device move; the wrappers then construct on
+    the CPU and consume the random generator exactly as on a GPU box."""
+    def init_net_cpu(net, init_type="normal"):
+        net = torch.nn.DataParallel(net)
+        N.init_weights(net, init_type)
+        return net
+    N.init_net = init_net_cpu
+
+
 def build(N, P, y, z, seed, ngf, oracle_init, n_stage=4):
-    """The reference's inner nets with the wrappers' ctor arguments
-    (networks.py:82, :60; ngf is 64 there, smaller here for the tiny case).
-    oracle_init=True overwrites the reference's own kaiming draw with
-    oracle.init_params(seed) so that the fixture need not store the weights."""
+    """The reference's inner nets with the wrappers' ctor arguments (networks.py:82, :60; ngf is
+    64 there, smaller here for the tiny cases), constructed and initialised in the wrappers' order
+    (cvae.py:57-58: encoder constructed + init_weights, then decoder constructed + init_weights).
+    oracle_init=True: the fixture does not store the initial weights; oracle.init_params(seed)
+    must then reproduce the reference's draw bit for bit, which is asserted here."""
     torch.manual_seed(seed)
     norm = N.get_norm_layer("batch")
     nl = N.get_non_linearity("lrelu")
     enc = N.ResNetEncoder(P, 3 + y, 2 * z, ngf, n_stage, norm, nl)
+    N.init_weights(torch.nn.DataParallel(enc), "kaiming")
     dec = N.ConvUpSampleDecoder(P, z + y, ngf, n_stage, norm, nl)
-    N.init_weights(enc, "kaiming")
-    N.init_weights(dec, "kaiming")
+    N.init_weights(torch.nn.DataParallel(dec), "kaiming")
     if oracle_init:
         e, d = O.init_params(P, y, z, seed=seed, ngf=ngf, n_stage=n_stage)
-        enc.load_state_dict({k[len(O.EP):]: v for k, v in e.items()})
-        dec.load_state_dict({k[len(O.DP):]: v for k, v in d.items()})
+        for k, v in enc.state_dict().items():
+            assert torch.equal(v, e[O.EP + k]), "oracle init differs from the reference at " + k
+        for k, v in dec.state_dict().items():
+            assert torch.equal(v, d[O.DP + k]), "oracle init differs from the reference at " + k
     return enc, dec
+
+
+def init_case(N, name, P, y, z, seed):
+    """Seed parity of the initialisation and the checkpoint key names, from the reference's own
+    wrapper classes: torch.manual_seed(seed); encoder(args); decoder(args) (cvae.py:57-58), then
+    the state dicts cvae.py:234-235 saves (En.module.state_dict() with En = DataParallel(wrapper),
+    i.e. the wrapper's own state dict).  Stored per tensor: shape, a strided sample, sum, L2."""
+    wrappers_on_cpu(N)
+    args = _Args()
+    args.z_dim, args.y_dim, args.pix_dim, args.device = z, y, P, torch.device("cpu")
+    torch.manual_seed(seed)
+    En = torch.nn.DataParallel(N.encoder(args))
+    De = torch.nn.DataParallel(N.decoder(args))
+    out = {"meta": np.array([P, y, z, seed], dtype=np.int64)}
+    for half, sd in (("encoder", En.module.state_dict()), ("decoder", De.module.state_dict())):
+        out[half + "_keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out["shape/" + k] = np.array(tuple(v.shape), dtype=np.int64)
+            put(out, "init/" + k, v.detach().numpy(), small=False)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f MB" % (os.path.getsize(path) / 1e6), len(out["encoder_keys"]), "+",
+          len(out["decoder_keys"]), "keys; first:", out["encoder_keys"][0], out["decoder_keys"][0])
 
 
 def sd_with_prefix(net, prefix):
@@ -124,8 +162,8 @@ def _run_case(N, name, P, y, z, B, batch_size_flag, lr, seed, ngf, small, n_step
     out = {"meta": np.array(meta, dtype=np.int64),
            "lr": np.array(lr, dtype=np.float64)}
     if small:
-        out.update({"init/" + k: v for k, v in sd_with_prefix(enc, "encoder.module.").items()})
-        out.update({"init/" + k: v for k, v in sd_with_prefix(dec, "decoder.module.").items()})
+        out.update({"init/" + k: v for k, v in sd_with_prefix(enc, O.EP).items()})
+        out.update({"init/" + k: v for k, v in sd_with_prefix(dec, O.DP).items()})
 
     g = torch.Generator().manual_seed(seed + 1000)
     drop_mod = dec.fc[2]
@@ -184,15 +222,15 @@ def _run_case(N, name, P, y, z, B, batch_size_flag, lr, seed, ngf, small, n_step
             for k, v in acts.items():
                 put(out, "s0/act/" + k, v, small)
             for k, p in enc.named_parameters():
-                put(out, "s0/grad/encoder.module." + k, p.grad.detach().clone().numpy(), small)
+                put(out, "s0/grad/" + O.EP + k, p.grad.detach().clone().numpy(), small)
             for k, p in dec.named_parameters():
-                put(out, "s0/grad/decoder.module." + k, p.grad.detach().clone().numpy(), small)
+                put(out, "s0/grad/" + O.DP + k, p.grad.detach().clone().numpy(), small)
         opt.step()
         if step in (0, n_steps - 1):
             tag = "after%d/" % (step + 1)
-            for k, v in sd_with_prefix(enc, "encoder.module.").items():
+            for k, v in sd_with_prefix(enc, O.EP).items():
                 put(out, tag + k, v, small)
-            for k, v in sd_with_prefix(dec, "decoder.module.").items():
+            for k, v in sd_with_prefix(dec, O.DP).items():
                 put(out, tag + k, v, small)
     for h in hooks:
         h.remove()
@@ -242,6 +280,11 @@ def main():
     # "deeper stacks" variant of the 128 x 128 configuration, here at 64 x 64 -> 2 x 2 with ngf=8
     run_case(N, "deep5_p64_ngf8", P=64, y=5, z=8, B=4, batch_size_flag=4, lr=1e-3, seed=3,
              ngf=8, small=True, layer_taps=False, n_stage=5)
+    # initial state and checkpoint keys of the real wrapper classes (ngf 64, four stages) per seed
+    if not only or "init_p16_seed7" in only:
+        init_case(N, "init_p16_seed7", P=16, y=4, z=8, seed=7)
+    if not only or "init_c3_seed0" in only:
+        init_case(N, "init_c3_seed0", P=64, y=100, z=32, seed=0)
 
 
 if __name__ == "__main__":

@@ -79,7 +79,7 @@ def test_two_rank_allreduce_equals_dataparallel_step():
     e, d = c.init_state()
     x, labels, eps, mask = c.inputs(0)
     _, ref = O.dp_forward_backward(e, d, x, labels, eps, mask, c.y, c.bs_flag, world)
-    zero_grad = {"encoder.module.conv.1.bias", "encoder.module.fc.0.bias"}   # exactly 0 up to rounding noise
+    zero_grad = {"encoder.conv.1.bias", "encoder.fc.0.bias"}   # exactly 0 up to rounding noise
     for k in lay["order"]:
         if k in zero_grad:
             continue

@@ -110,7 +110,7 @@ def test_gan_trainer_runs_and_checkpoints(tmp_path):
     for name in ("encoder", "decoder", "discriminator", "classifier"):
         assert os.path.exists(os.path.join(d, "Synth_%s.pkl" % name)), name
     cl = torch.load(os.path.join(d, "Synth_classifier.pkl"), weights_only=True)
-    assert tuple(cl["head.weight"].shape) == (4, 64) and tuple(cl["encoder.module.conv.1.weight"].shape) == (64, 3, 7, 7)
+    assert tuple(cl["head.weight"].shape) == (4, 64) and tuple(cl["encoder.conv.1.weight"].shape) == (64, 3, 7, 7)
     m2 = CVAE(_args(tmp_path, resume=True, gan_type="CVAEGAN"))
     for k, v in m.gan.C.trunk.state_dict("critic").items():
         assert torch.equal(v, m2.gan.C.trunk.state_dict("critic")[k]), k

@@ -73,7 +73,7 @@ def test_reference_style_training_loop(name):
         assert abs(float(v) - ref) <= 2e-5 * abs(ref), (k, float(v), ref)
     ok, msg = compare(c.npz, "s0/dec", out.detach().cpu().numpy(), 1e-3, 3e-4)
     assert ok, msg
-    zero_grad = {"encoder.module.conv.1.bias", "encoder.module.fc.0.bias"}
+    zero_grad = {"encoder.conv.1.bias", "encoder.fc.0.bias"}
     for mod in (enc, dec):
         for k, p in mod.named_parameters():
             if k in zero_grad:

@@ -17,7 +17,7 @@ from parity import run_parity, format_rows
 
 pytestmark = pytest.mark.gpu
 
-ZERO_GRAD = {"encoder.module.conv.1.bias", "encoder.module.fc.0.bias"}   # true gradient is exactly 0
+ZERO_GRAD = {"encoder.conv.1.bias", "encoder.fc.0.bias"}   # true gradient is exactly 0
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -109,8 +109,8 @@ def test_trainer_runs_saves_and_reloads(tmp_path):
     enc = torch.load(os.path.join(d, "Synth_encoder.pkl"), weights_only=True)
     dec = torch.load(os.path.join(d, "Synth_decoder.pkl"), weights_only=True)
     assert len(enc) == 68 and len(dec) == 14               # the reference's checkpoint entries
-    assert tuple(enc["encoder.module.conv.1.weight"].shape) == (64, 3 + 4, 7, 7)
-    assert tuple(dec["decoder.module.conv.5.weight"].shape) == (3, 64, 7, 7)
+    assert tuple(enc["encoder.conv.1.weight"].shape) == (64, 3 + 4, 7, 7)
+    assert tuple(dec["decoder.conv.5.weight"].shape) == (3, 64, 7, 7)
     assert os.path.exists(os.path.join(d, "Synth_history.pkl"))
     pngs = [f for f in os.listdir(os.path.join(m.result_dir, m.model_dir)) if f.endswith(".png")]
     assert len(pngs) == 4

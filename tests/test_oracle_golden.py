@@ -117,3 +117,32 @@ def test_label_fold_identity():
     cls_bias = w[:, 3:].sum(dim=(2, 3))            # [Cout, y]
     folded = img + cls_bias.t()[labels][:, :, None, None]
     assert (dense - folded).abs().max().item() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["init_p16_seed7", "init_c3_seed0"])
+def test_init_matches_reference_seed_and_checkpoint_keys(name):
+    """torch.manual_seed(s); encoder(args); decoder(args) (models/cvae.py:57-58), recorded from the
+    reference's own wrapper classes: the oracle's and the engine's initialisers must reproduce
+    every tensor bit for bit from the same seed, under the same checkpoint keys, in the same
+    order, with the same shapes (models/cvae.py:234-235 saves exactly these dicts)."""
+    import os
+    from helpers import GOLDEN
+    from oracle.fixtures import compact
+    from cvae_gan_amd.engine import init_state, param_shapes
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    P, y, zd, seed = [int(v) for v in z["meta"]]
+    ref_keys = [str(k) for k in z["encoder_keys"]], [str(k) for k in z["decoder_keys"]]
+    for what, (e, d) in (("oracle", O.init_params(P, y, zd, seed=seed)), ("engine", init_state(P, y, zd, seed=seed))):
+        for half, keys in zip((e, d), ref_keys):
+            assert list(half.keys()) == keys, what
+            for k in keys:
+                assert tuple(half[k].shape) == tuple(int(v) for v in z["shape/" + k]), (what, k)
+                got = compact(half[k].numpy())
+                if "full" in got:
+                    assert np.array_equal(got["full"], z["init/" + k + "#full"]), (what, k)
+                else:
+                    assert np.array_equal(got["sample"], z["init/" + k + "#sample"]), (what, k)
+                    assert float(got["sum"]) == float(z["init/" + k + "#sum"]), (what, k)
+                    assert float(got["l2"]) == float(z["init/" + k + "#l2"]), (what, k)
+    es, ds = param_shapes(P, y, zd)
+    assert list(es) == ref_keys[0] and list(ds) == ref_keys[1]
