@@ -24,7 +24,7 @@ struct RedArgs {
     const float* beta;
     float* ws;           // partials [2][nblk][C]
     int M, C, ld, nblk;
-    int Cb;              // columns handled per blockIdx.y (== C unless C > 1024)
+    int Cb;              // columns handled per blockIdx.y (== C unless C > 1024; the last block may be ragged)
 };
 
 template <typename T, int MODE>
@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     const int RL = blockDim.x / CC;
     const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
     const int c_off = blockIdx.y * a.Cb;
+    const bool col_ok = c_off + chunk * 8 < a.C;          // C is a multiple of 8: a chunk is whole or absent
     __shared__ float sm[2][256][8];
     float s0[8], s1[8];
 #pragma unroll
@@ -43,13 +44,13 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
     if (MODE == RED_BNBWD || from_x || plain) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c_off + chunk * 8 + j;
+            const int c = col_ok ? c_off + chunk * 8 + j : 0;
             mean[j] = a.stats[c]; istd[j] = a.stats[a.C + c];
             sc[j] = sh[j] = 0.f;
             if (from_x) { sc[j] = a.gamma[c] * istd[j]; sh[j] = a.beta[c] - mean[j] * sc[j]; }   // as bn_act_fwd
         }
     }
-    if (rl < RL) {
+    if (rl < RL && col_ok) {
         // two rows per trip: their loads are issued together (twice the bytes in flight per thread),
         // the sums are taken in row order, so the result does not depend on the pairing
         const int NQ = (MODE == RED_BNBWD) ? 3 : ((MODE == RED_BNBWD_X || plain) ? 2 : 1);
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
         const int ch = col / 8, j = col % 8;
         float s = 0.f;
         for (int r = 0; r < RL; ++r) s += sm[which][r * CC + ch][j];
-        a.ws[((size_t)which * a.nblk + blockIdx.x) * a.C + c_off + col] = s;
+        if (c_off + col < a.C) a.ws[((size_t)which * a.nblk + blockIdx.x) * a.C + c_off + col] = s;
     }
 }
 
@@ -177,11 +178,12 @@ __global__ void __launch_bounds__(256) sum_finalize(const float* __restrict__ ws
 // ---- BatchNorm + LeakyReLU apply -------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) bn_act_fwd(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                                  int M, int C, const float* __restrict__ stats,
+                                                  int M, int C, int Cb, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta) {
-    const int CC = C / 8, RL = blockDim.x / CC;
-    const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
-    if (rl >= RL) return;
+    // Cb columns per blockIdx.y (== C unless C > 1024); `chunk` is the 8-column chunk within the row
+    const int CC = Cb / 8, RL = blockDim.x / CC;
+    const int chunk = blockIdx.y * CC + threadIdx.x % CC, rl = threadIdx.x / CC;
+    if (rl >= RL || chunk * 8 >= C) return;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -210,14 +212,14 @@ __global__ void __launch_bounds__(256) bn_act_fwd(const T* __restrict__ x, const
 // GATE 0: sign of y; 1: sign of gamma*xhat + beta, recomputed as bn_act_fwd does; 2: none (dy is already gated)
 template <typename T, int GATE>
 __global__ void __launch_bounds__(256) bn_act_bwd_dx(const T* __restrict__ dy, const T* __restrict__ y,
-                                                     const T* __restrict__ x, T* __restrict__ dx, int M, int C,
+                                                     const T* __restrict__ x, T* __restrict__ dx, int M, int C, int Cb,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
     constexpr bool from_x = GATE == 1;
-    const int CC = C / 8, RL = blockDim.x / CC;
-    const int chunk = threadIdx.x % CC, rl = threadIdx.x / CC;
-    if (rl >= RL) return;
+    const int CC = Cb / 8, RL = blockDim.x / CC;
+    const int chunk = blockIdx.y * CC + threadIdx.x % CC, rl = threadIdx.x / CC;
+    if (rl >= RL || chunk * 8 >= C) return;
     float mean[8], istd[8], k0[8], k1[8], k2[8], sh[8];
     const float invM = 1.f / (float)M;
 #pragma unroll
@@ -1003,7 +1005,7 @@ int red_blocks(int M, int C) {
     return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
 }
 int check_rows(const char* who, int M, int C) {
-    CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && C <= 1024, "%s: M %d C %d (C must be a multiple of 8, <= 1024)", who, M, C);
+    CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && C <= 65535 * 512, "%s: M %d C %d (C must be a positive multiple of 8)", who, M, C);
     return 0;
 }
 int col_block(int C) { return C <= 1024 ? C : 512; }
@@ -1032,15 +1034,16 @@ int cvg_image_u8_to_f32(const uint8_t* hwc, float* nchw, int32_t B, int32_t P, c
     return 0;
 }
 
-int32_t cvg_bn_stats_blocks(int32_t M, int32_t C) { return red_blocks(M, C); }
+int32_t cvg_bn_stats_blocks(int32_t M, int32_t C) { return red_blocks(M, col_block(C)); }
 
 int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats, float* running_mean,
                  float* running_var, int64_t* nbt, float* ws, cvg_stream stream) {
     if (check_rows("bn_stats", M, C)) return -1;
     CVG_CHECK(x && stats && ws, "bn_stats: null");
     hipStream_t s = (hipStream_t)stream;
-    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
-    DISPATCH(dtype, colreduce<T, RED_STATS><<<a.nblk, red_threads(C), 0, s>>>(a));
+    const int Cb = col_block(C);
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, Cb), Cb};
+    DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
     CVG_LAUNCH_CHECK();
@@ -1065,11 +1068,11 @@ int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32
                    const float* gamma, const float* beta, cvg_stream stream) {
     if (check_rows("bn_act_fwd", M, C)) return -1;
     CVG_CHECK(x && y && stats && gamma && beta, "bn_act_fwd: null");
-    const int RL = 256 / (C / 8);
+    const int Cb = col_block(C), RL = 256 / (Cb / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
     if (nb > 4096) nb = 4096;
-    DISPATCH(dtype, bn_act_fwd<T><<<nb, red_threads(C), 0, (hipStream_t)stream>>>((const T*)x, (const T*)res, (T*)y, M, C,
-                                                                                 stats, gamma, beta));
+    DISPATCH(dtype, bn_act_fwd<T><<<dim3(nb, ceil_div(C, Cb)), red_threads(Cb), 0, (hipStream_t)stream>>>(
+                        (const T*)x, (const T*)res, (T*)y, M, C, Cb, stats, gamma, beta));
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -1080,19 +1083,21 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
     if (check_rows("bn_act_bwd", M, C)) return -1;
     CVG_CHECK(dy && x && dx && stats && gamma && dgamma && dbeta && ws, "bn_act_bwd: null");
     hipStream_t s = (hipStream_t)stream;
-    RedArgs a = {x, dy, y, stats, gamma, beta, ws, M, C, C, red_blocks(M, C), C};
+    const int Cb = col_block(C);
+    RedArgs a = {x, dy, y, stats, gamma, beta, ws, M, C, C, red_blocks(M, Cb), Cb};
     const int gate = y ? 0 : (beta ? 1 : 2);     // no y and no beta: dy is already gated
-    if (gate == 0) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<a.nblk, red_threads(C), 0, s>>>(a));
-    else if (gate == 1) DISPATCH(dtype, colreduce<T, RED_BNBWD_X><<<a.nblk, red_threads(C), 0, s>>>(a));
-    else DISPATCH(dtype, colreduce<T, RED_BNBWD_PLAIN><<<a.nblk, red_threads(C), 0, s>>>(a));
+    const dim3 rgrid(a.nblk, ceil_div(C, Cb));
+    if (gate == 0) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<rgrid, red_threads(Cb), 0, s>>>(a));
+    else if (gate == 1) DISPATCH(dtype, colreduce<T, RED_BNBWD_X><<<rgrid, red_threads(Cb), 0, s>>>(a));
+    else DISPATCH(dtype, colreduce<T, RED_BNBWD_PLAIN><<<rgrid, red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
     CVG_LAUNCH_CHECK();
-    const int RL = 256 / (C / 8);
+    const int RL = 256 / (Cb / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
     if (nb > 4096) nb = 4096;
-#define BN_DX(G) DISPATCH(dtype, bn_act_bwd_dx<T, G><<<nb, red_threads(C), 0, s>>>((const T*)dy, (const T*)y, (const T*)x, \
-                                                                                 (T*)dx, M, C, stats, gamma, beta, dgamma, dbeta))
+#define BN_DX(G) DISPATCH(dtype, bn_act_bwd_dx<T, G><<<dim3(nb, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>( \
+                              (const T*)dy, (const T*)y, (const T*)x, (T*)dx, M, C, Cb, stats, gamma, beta, dgamma, dbeta))
     if (gate == 0) BN_DX(0);
     else if (gate == 1) BN_DX(1);
     else BN_DX(2);
@@ -1103,12 +1108,12 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
 
 int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, float* out, int32_t md, int32_t ma,
                int32_t mb, float* ws, cvg_stream stream) {
-    CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && (C <= 1024 || C % 512 == 0), "colsum: C %d must be <= 1024 or a multiple of 512", C);
+    CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && C <= 65535 * 512, "colsum: C %d must be a positive multiple of 8", C);
     CVG_CHECK(x && out && ws && ld >= C && ld % 8 == 0 && md > 0, "colsum: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
     RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
-    DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, C / Cb), red_threads(Cb), 0, s>>>(a));
+    DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
     CVG_LAUNCH_CHECK();
@@ -1132,6 +1137,7 @@ int cvg_label_bias(const float* w, float* cbias, int32_t cout, int32_t y_dim, cv
 int cvg_label_bias_bwd(const void* dy, int32_t dtype, const int32_t* labels, int32_t B, int32_t pixels, int32_t cout,
                        int32_t y_dim, float* dw, float* dbias, float* ws, cvg_stream stream) {
     if (check_rows("label_bias_bwd", pixels, cout)) return -1;
+    CVG_CHECK(cout <= 1024, "label_bias_bwd: at most 1024 stem channels (got %d)", cout);
     CVG_CHECK(dy && labels && dw && ws && B > 0, "label_bias_bwd: null");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype, per_image_colsum<T><<<B, red_threads(cout), 0, s>>>((const T*)dy, ws, pixels, cout));

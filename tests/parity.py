@@ -163,3 +163,60 @@ def format_rows(rows):
     for kind, k, r, m, c in rows:
         out.append("%-5s %-46s rel_err %.3e  ref_max %.3e  cos %.6f" % (kind, k, r, m, c))
     return "\n".join(out)
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded synthetic cases at sizes no fixture covers (the oracle is run on the spot)
+# ---------------------------------------------------------------------------------------------------
+ZERO_GRAD_KEYS = (O.EP + "conv.1.bias", O.EP + "fc.0.bias")     # a bias in front of a BatchNorm: true gradient 0
+
+
+def synthetic_inputs(P, Y, Z, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, P, P, generator=g) * 2 - 1
+    labels = torch.randint(0, Y, (B,), generator=g)
+    eps = torch.randn(B, Z, generator=g)
+    mask = (torch.rand(B, 4 * (Z + Y), generator=g) > 0.5).float()
+    return x, labels, eps, mask
+
+
+def synthetic_state(P, Y, Z, init_seed, ngf=64, n_stage=4, dec_scale=0.55):
+    """The reference's seeded initialisation with every decoder weight scaled by dec_scale, which
+    brings the generator's pre-tanh activations to O(1): at the raw initialisation the tanh is
+    saturated and every gradient is ~1e-9 of its conditioned size."""
+    e, d = O.init_params(P, Y, Z, seed=init_seed, ngf=ngf, n_stage=n_stage)
+    d = OrderedDict((k, v * dec_scale if k.endswith("weight") else v) for k, v in d.items())
+    return e, d
+
+
+def synthetic_parity(P, Y, Z, B, dtype, seed=3, init_seed=5, ngf=64, n_stage=4, dec_scale=0.55, lr=1e-4):
+    """One train step of the oracle and of the engine on the same seeded inputs.
+    -> dict(loss={k: rel err}, dec_err (max abs), dec_cos, h_cos, grads={key: (err / max|ref|, cosine)}, eng, ref)"""
+    from cvae_gan_amd.engine import Engine
+    x, labels, eps, mask = synthetic_inputs(P, Y, Z, B, seed)
+    e, d = synthetic_state(P, Y, Z, init_seed, ngf, n_stage, dec_scale)
+    st = O.TrainState(OrderedDict((k, v.clone()) for k, v in e.items()), OrderedDict((k, v.clone()) for k, v in d.items()))
+    ref = O.train_step(st, x, labels, eps, mask, Y, float(B), lr)
+    state = OrderedDict(e)
+    state.update(d)
+    eng = Engine(P, Y, Z, B, dtype=dtype, ngf=ngf, n_stage=n_stage, state=state)
+    eng.set_mask(mask)
+    dec = eng.forward_backward(x.cuda(), labels.int().cuda(), eps.cuda(), float(B))
+    torch.cuda.synchronize()
+    got = eng.read_losses()
+    out = {"loss": {k: abs(got[k] - float(ref[k])) / max(abs(float(ref[k])), 1e-3) for k in ("KL", "LL")},
+           "dec_err": float((dec.cpu() - ref["dec"]).abs().max()), "dec_cos": cosine(dec.cpu(), ref["dec"]),
+           "h_cos": cosine(eng.enc["h"].float().cpu(), ref["h_enc"]), "grads": {}, "eng": eng, "ref": ref, "state": (e, d),
+           "inputs": (x, labels, eps, mask)}
+    for k, gref in ref["grads"].items():
+        if k in ZERO_GRAD_KEYS:
+            continue
+        out["grads"][k] = (rel_err(eng.grads[k].cpu(), gref)[0], cosine(eng.grads[k].cpu(), gref))
+    return out
+
+
+def worst_grads(res):
+    """(key, err) with the largest relative error and (key, cos) with the smallest cosine."""
+    we = max(res["grads"].items(), key=lambda kv: kv[1][0])
+    wc = min(res["grads"].items(), key=lambda kv: kv[1][1])
+    return (we[0], we[1][0]), (wc[0], wc[1][1])

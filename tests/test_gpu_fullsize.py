@@ -5,6 +5,13 @@
   every parameter gradient within 5e-3 of the tensor's maximum and at cosine >= 0.9999 (sums over
   131k pixels behind nine BatchNorm backward passes in two different orders; biases in front of a
   BatchNorm, whose true gradient is zero, excluded).
+* bf16 mode at batch 32 against the same oracle step: the mode and width the benchmark is quoted in.
+  Tolerances: both losses within 3e-2 relative, encoder output and reconstruction at cosine >= 0.998
+  with the f32 oracle, every parameter gradient at cosine >= 0.98 (decoder weights scaled by 0.55 on
+  both sides as in the f32 test, so that the tanh is not saturated and gradients are O(1)).
+* 128 x 128 (the paper-scale configurations): f32 at batch 4 against the oracle with four and with
+  five down / up stages at ngf 64, the eval-mode encoder + decoder forward and the decoder-only
+  sampling path against the oracle in eval mode, and the bf16 full-batch (64) step for determinism.
 * bf16 mode at the full batch of 256, where the oracle would take minutes, through properties that do
   not depend on size: the step is run-to-run bit-identical, and the backward pass is linear in the
   loss scale (a scale of 2 doubles every gradient exactly: powers of two commute with rounding).
@@ -63,6 +70,90 @@ def test_c3_width_f32_matches_oracle():
             worst_cos = (k, cos)
     assert worst[1] <= 5e-3, worst
     assert worst_cos[1] >= 0.9999, worst_cos
+
+
+def test_c3_width_bf16_matches_oracle():
+    from parity import synthetic_parity, worst_grads
+    r = synthetic_parity(P, Y, Z, 32, torch.bfloat16, seed=3, init_seed=5)
+    (wk, werr), (ck, wcos) = worst_grads(r)
+    print("c3 bf16 B=32: loss err", r["loss"], "dec cos %.5f h cos %.5f" % (r["dec_cos"], r["h_cos"]),
+          "worst grad err", wk, "%.3e" % werr, "worst grad cos", ck, "%.5f" % wcos)
+    assert r["loss"]["KL"] <= 3e-2 and r["loss"]["LL"] <= 3e-2, r["loss"]
+    assert r["h_cos"] >= 0.998 and r["dec_cos"] >= 0.998, (r["h_cos"], r["dec_cos"])
+    assert wcos >= 0.98, (ck, wcos)
+
+
+@pytest.mark.parametrize("n_stage", [4, 5])
+def test_p128_f32_matches_oracle(n_stage):
+    """BASELINE configuration 4 (128 x 128, 100 classes, ngf 64) with the wrappers' four stages and with
+    the "deeper stacks" five, at batch 4."""
+    from parity import synthetic_parity, worst_grads
+    r = synthetic_parity(128, Y, Z, 4, torch.float32, seed=8, init_seed=9, n_stage=n_stage)
+    (wk, werr), (ck, wcos) = worst_grads(r)
+    print("P128 f32 stages %d: loss err" % n_stage, r["loss"], "dec err %.2e" % r["dec_err"],
+          "worst grad err", wk, "%.3e" % werr, "worst grad cos", ck, "%.6f" % wcos)
+    assert r["loss"]["KL"] <= 2e-5 and r["loss"]["LL"] <= 2e-5, r["loss"]
+    assert r["dec_err"] <= 1e-4
+    assert werr <= 5e-3, (wk, werr)
+    assert wcos >= 0.9999, (ck, wcos)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_p128_eval_paths_match_oracle(dtype):
+    """BASELINE configuration 5's path (models/cvae.py:197-220 and :167-178) at 128 x 128: eval-mode
+    encoder + sampler + decoder, and the decoder alone on given latents, against the oracle with
+    train=False (running statistics, no dropout).  f32: 1e-4 of the output range; bf16: cosine >= 0.998."""
+    from cvae_gan_amd.engine import Engine
+    from oracle import ref_cpu as O
+    from parity import synthetic_inputs, synthetic_state, cosine
+    B, PP = 4, 128
+    x, labels, eps, _ = synthetic_inputs(PP, Y, Z, B, 12)
+    e, d = synthetic_state(PP, Y, Z, 13)
+    # running statistics that are not the constructor's (0, 1), so that the eval path really reads them
+    g = torch.Generator().manual_seed(14)
+    for k in e:
+        if k.endswith("running_mean"):
+            e[k] = 0.1 * torch.randn(e[k].shape, generator=g)
+        elif k.endswith("running_var"):
+            e[k] = 0.5 + torch.rand(e[k].shape, generator=g)
+    with torch.no_grad():
+        full_ref, _, _, _ = O.cvae_forward(e, d, x, labels, eps, None, Y, train=False)
+        zs = torch.randn(B, Z, generator=g)
+        dec_ref = O.decoder_forward(d, zs, O.one_hot(labels, Y), None, train=False)
+    state = OrderedDict(e)
+    state.update(d)
+    eng = Engine(PP, Y, Z, B, dtype=dtype, state=state)
+    eng.training = False
+    full = eng.reconstruct(x.cuda(), labels.int().cuda(), eps.cuda()).cpu().clone()
+    dec = eng.decode(zs.cuda(), O.one_hot(labels, Y).cuda()).cpu().clone()
+    if dtype == torch.float32:
+        assert float((full - full_ref).abs().max()) <= 1e-4
+        assert float((dec - dec_ref).abs().max()) <= 1e-4
+    else:
+        assert cosine(full, full_ref) >= 0.998 and cosine(dec, dec_ref) >= 0.998, (cosine(full, full_ref), cosine(dec, dec_ref))
+
+
+def test_c4_full_batch_bf16_is_deterministic():
+    """128 x 128 at the configuration's per-GPU batch of 64, bf16, four and five stages: finite,
+    non-zero and run-to-run bit-identical gradients and losses."""
+    from cvae_gan_amd.engine import Engine
+    from parity import synthetic_inputs
+    for n_stage in (4, 5):
+        B = 64
+        x, labels, eps, mask = synthetic_inputs(128, Y, Z, B, 21)
+        x, labels, eps = x.cuda(), labels.int().cuda(), eps.cuda()
+        eng = Engine(128, Y, Z, B, dtype=torch.bfloat16, seed=2, n_stage=n_stage)
+        eng.set_mask(mask)
+        runs = []
+        for _ in range(2):
+            eng.forward_backward(x, labels, eps, float(B))
+            torch.cuda.synchronize()
+            runs.append((eng.g_arena.clone(), eng.losses[:2].clone()))
+        assert torch.isfinite(runs[0][0]).all() and float(runs[0][0].abs().max()) > 0
+        assert torch.isfinite(runs[0][1]).all()
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        del eng
+        torch.cuda.empty_cache()
 
 
 def test_c3_full_batch_bf16_is_deterministic_and_linear():

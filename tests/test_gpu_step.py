@@ -106,3 +106,17 @@ def test_three_steps_f32_match_golden():
             refv = float(c.npz["s%d/%s" % (step, k)])
             tol = 2e-5 if step == 0 else 2e-3     # AdamW's first steps amplify rounding (sign of ~0 gradients)
             assert abs(got[k] - refv) <= tol * abs(refv), (step, k, got[k], refv)
+
+
+@pytest.mark.parametrize("z,y", [(260, 21), (256, 16)])
+def test_wide_latent_and_label_dims_f32(z, y):
+    """Channel counts beyond 1024 that are no multiple of 512 in the row kernels: the encoder head's
+    BatchNorm1d over 4 z features (1040 for z = 260) and the decoder's first Linear over 4 (z + y)
+    (1124 -> padded to 1128).  The reference's own command-line defaults (z_dim 256, y_dim 1000,
+    starter.py:25-26) are of this kind.  f32 against the oracle at 16 x 16, ngf 8."""
+    from parity import synthetic_parity, worst_grads
+    r = synthetic_parity(16, y, z, 6, torch.float32, seed=31, init_seed=32, ngf=8)
+    (wk, werr), (ck, wcos) = worst_grads(r)
+    assert r["loss"]["KL"] <= 2e-5 and r["loss"]["LL"] <= 2e-5, r["loss"]
+    assert r["dec_err"] <= 1e-4
+    assert werr <= 2e-3 and wcos >= 0.9999, ((wk, werr), (ck, wcos))
