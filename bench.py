@@ -130,7 +130,7 @@ class KernelTimer:
         agg = {}
         for name, fl, a, b, g in self.records:
             d = g.desc
-            key = (g.key.replace("encoder.", "E.").replace("decoder.", "D."), name,
+            key = (("E." + g.key[8:]) if g.key.startswith("encoder.") else ("D." + g.key[8:]) if g.key.startswith("decoder.") else g.key, name,
                    d.B * d.OH * d.OW, d.N, d.ntaps * d.Cin, d.stride, d.oy_off * 2 + d.ox_off, id(g))
             s = agg.setdefault(key, [fl, 0.0])
             s[1] += a.elapsed_time(b) * 1e-3 / reps
@@ -214,7 +214,7 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if world > 1:
-        backend = os.environ.get("CVG_BENCH_BACKEND", "nccl")          # "gloo": rehearsal of N > 1 on one GPU
+        backend = os.environ.get("CVG_BENCH_BACKEND") or os.environ.get("CVG_DDP_BACKEND", "nccl")   # "gloo": rehearsal of N > 1 on one GPU
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
@@ -244,43 +244,26 @@ def main():
     loss_scale = 1.0 / world
 
     # N > 1: the gradient arena is exchanged in three ranges (it is laid out in the order backward
-    # finishes gradients), each as one SUM all-reduce on a side stream: the decoder's (33 MB at c3)
-    # travels while the encoder's head and deep blocks run backward, theirs (45 MB: nearly all of the
-    # encoder's parameters) while the shallow blocks and the stem run, which are the longest part of
-    # the encoder's backward pass; only the last range (1.5 MB) is exposed.
+    # finishes gradients), each as one SUM all-reduce on a side stream, by the same GradSync the trainer
+    # uses: the decoder's (33 MB at c3) travels while the encoder's head and deep blocks run backward,
+    # theirs (45 MB: nearly all of the encoder's parameters) while the shallow blocks and the stem run,
+    # which are the longest part of the encoder's backward pass; only the last range (1.5 MB) is exposed.
     force_ddp = os.environ.get("CVG_BENCH_FORCE_DDP") is not None      # rehearse the N > 1 control flow on one rank
     multi = world > 1 or force_ddp
-    ranges = ddp.stage_ranges(eng.arena_order, eng.arena_offsets, eng.arena_numel)
-    dec_lo, dec_hi = ranges["dec"]
-    assert dec_lo == 0, "the decoder's gradients lead the arena"
-    up_lo, up_hi = eng.enc_upper_range()
-    assert up_lo == dec_hi, "the encoder's head follows the decoder in the arena"
-    comm = torch.cuda.Stream() if multi else None
-
-    def exchange(lo, hi):
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev)
-            if dist.is_initialized() and dist.get_backend() == "nccl":
-                dist.all_reduce(eng.g_arena[lo:hi], op=dist.ReduceOp.SUM)
-            elif world > 1:                  # rehearsal backends reduce a host copy
-                comm.synchronize()
-                host = eng.g_arena[lo:hi].cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                eng.g_arena[lo:hi].copy_(host)
+    sync = ddp.GradSync.for_engine(eng) if multi else None
+    if multi:
+        (dec_lo, dec_hi), (up_lo, up_hi) = eng.arena_range("dec"), eng.enc_upper_range()
+        assert dec_lo == 0 and up_lo == dec_hi, "arena order: decoder, encoder head + deep blocks, the rest"
 
     def step(i):
         x, labels, eps = batches[i % len(batches)]
         eng.random_mask()
         if multi:
-            eng.forward_backward_decoder(x, labels, eps, batch_size_flag, loss_scale)
-            exchange(dec_lo, dec_hi)
-            eng.enc_backward(eng.enc["dh"], part="upper")
-            exchange(up_lo, up_hi)
-            eng.enc_backward(eng.enc["dh"], part="lower")
-            exchange(up_hi, eng.arena_numel)
-            torch.cuda.current_stream().wait_stream(comm)
+            sync.begin_step()
+            eng.grad_ready = sync.on_ready                   # exchanges start as backward reports its stages
+            eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
+            eng.grad_ready = None
+            sync.finish()
         else:
             eng.forward_backward(x, labels, eps, batch_size_flag, loss_scale)
         note("step %d enqueued" % i)
@@ -330,14 +313,16 @@ def main():
                 eng.adamw_step(args.lr)
 
             def run_graphs():
+                sync.begin_step()
                 g_head.replay()
-                exchange(dec_lo, dec_hi)
+                sync.group_ready(0)                          # the decoder's range
                 g_enc.replay()
-                exchange(up_lo, up_hi)
+                sync.group_ready(1)                          # encoder head + deep blocks
                 g_enc2.replay()
-                exchange(up_hi, eng.arena_numel)
-                torch.cuda.current_stream().wait_stream(comm)
+                sync.group_ready(2)                          # shallow blocks + stem
+                sync.finish()
                 g_opt.replay()
+            assert sync.groups[1][-1] == "enc.blk%d" % eng.enc_split, "graph boundaries follow the exchange groups"
         eng.step_count = saved
 
         def step(i):                                    # noqa: F811

@@ -11,7 +11,12 @@ What differs, on purpose:
 * the one-hot label planes of cvae.py:129 are never built (labels go in as class indices);
 * eps comes from the device RNG (the reference draws it with numpy on the host, networks.py:30);
 * visdom plots are skipped when visdom is not importable; image grids are written with PIL;
-* multi-GPU is one process per GPU (torchrun) with cvae_gan_amd.ddp, not nn.DataParallel."""
+* multi-GPU is one process per GPU with cvae_gan_amd.ddp, not nn.DataParallel: `--gpus 0,1` makes the
+  starter launch one rank per listed GPU (or run it under torchrun yourself); --batch_size stays the
+  GLOBAL batch as in the reference, rank r trains on rows [r*B/N, (r+1)*B/N) of every batch with
+  per-replica BatchNorm statistics, gradients are all-reduced over RCCL while backward is still
+  running, and rank 0 prints, samples and writes the checkpoints (DataParallel keeps replica 0's
+  BatchNorm buffers too)."""
 import os
 import pickle
 import random
@@ -21,6 +26,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
+from . import ddp
 from .datasets import make_dataset, DevicePrefetcher
 from .engine import Engine, ADAM_BETAS, ADAM_EPS
 
@@ -62,6 +68,14 @@ class CVAE(object):
         self.max_iters = getattr(args, "max_iters", 0)           # 0: whole epochs
         dtype = getattr(args, "dtype", "bf16")
         self.dtype = torch.float32 if dtype in ("f32", torch.float32) else torch.bfloat16
+        # data parallel: the process group is up before the trainer is built (starter.py); without one
+        # this is a single replica
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        if self.batch_size % self.world:
+            raise ValueError("--batch_size %d does not split over %d ranks" % (self.batch_size, self.world))
+        self.local_batch = self.batch_size // self.world
+        seed = getattr(args, "seed", 0)
 
         # loader items are uint8 images + class indices; normalisation and layout happen on the GPU
         # behind a pinned, double-buffered copy (set args.device_preprocess = False for the
@@ -70,30 +84,43 @@ class CVAE(object):
         self.train_data, self.synthetic = make_dataset(args.data_dir, args.dataset, args.pix_dim, args.y_dim,
                                                        max_size=args.data_size, raw=self.device_preprocess)
         if self.synthetic:
-            print("data directory %r has no %r listing: using the synthetic stand-in"
-                  % (args.data_dir, args.dataset))
-        print("Trainset: %d \n" % len(self.train_data))
-        self.trainset_loader = DataLoader(dataset=self.train_data, batch_size=args.batch_size, drop_last=True,
-                                          shuffle=True, num_workers=getattr(args, "worker", 0), pin_memory=True)
+            self._print("data directory %r has no %r listing: using the synthetic stand-in"
+                        % (args.data_dir, args.dataset))
+        self._print("Trainset: %d \n" % len(self.train_data))
+        if self.world == 1:
+            self.trainset_loader = DataLoader(dataset=self.train_data, batch_size=args.batch_size, drop_last=True,
+                                              shuffle=True, num_workers=getattr(args, "worker", 0), pin_memory=True)
+        else:
+            self.trainset_loader = DataLoader(
+                dataset=self.train_data, num_workers=getattr(args, "worker", 0), pin_memory=True,
+                batch_sampler=ddp.ShardedBatchSampler(len(self.train_data), self.batch_size, self.rank, self.world, seed=seed))
 
         # --gan_type CVAEGAN (starter.py:31 declares the flag, the reference never reads it): the adversarial step of cvae_gan_amd/gan.py (discriminator + classifier next to the
         # CVAE; no counterpart in the reference's trainer); self.engine stays the CVAE either way
         self.gan = None
         if getattr(args, "gan", False) or getattr(args, "gan_type", "VAE").upper() in ("CVAEGAN", "CVAE-GAN", "GAN"):
+            if self.world > 1:
+                raise NotImplementedError("--gan_type CVAEGAN trains on one GPU: the critics' gradients have no exchange yet")
             from .gan import CVAEGAN
             self.gan = CVAEGAN(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
-                               device=self.device, seed=getattr(args, "seed", 0),
+                               device=self.device, seed=seed,
                                lam_gd=getattr(args, "lam_gd", 1e-3), lam_gc=getattr(args, "lam_gc", 1e-3))
             self.engine = self.gan.vae
         else:
-            self.engine = Engine(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
-                                 device=self.device, seed=getattr(args, "seed", 0))
+            self.engine = Engine(self.pix_dim, self.y_dim, self.z_dim, self.local_batch, dtype=self.dtype,
+                                 device=self.device, seed=seed)
         self._sample_engine = None
+        self.sync = None
+        if self.world > 1:
+            ddp.broadcast_state(self.engine)                      # every replica starts from rank 0's state
+            self.sync = ddp.GradSync.for_engine(self.engine)
+            self.engine.grad_ready = self.sync.on_ready
+        self._eps_gen = torch.Generator(device=self.device).manual_seed(seed * 7919 + 17 + self.rank)
         if getattr(args, "resume", False):
             try:
                 self.load()
             except FileNotFoundError:
-                print("no checkpoint to resume from in", os.path.join(self.save_dir, self.model_dir))
+                self._print("no checkpoint to resume from in", os.path.join(self.save_dir, self.model_dir))
         if getattr(args, "testmode", False):
             self.load(args.pkl if getattr(args, "pkl", "") else None)
 
@@ -107,12 +134,18 @@ class CVAE(object):
         self.sample_y_[torch.arange(n), torch.arange(n) % self.y_dim] = 1
         self.train_hist = {}
 
+    def _print(self, *a):
+        if self.rank == 0:
+            print(*a, flush=True)
+
     # ------------------------------------------------------------------ checkpoints
     @property
     def model_dir(self):
         return "VAE_data_{}_pix_{}_batch_{}_embed_{}".format(self.dataset, self.pix_dim, self.batch_size, self.z_dim)
 
     def save(self):
+        if self.rank != 0:                                        # rank 0's replica is the checkpoint
+            return
         save_dir = check_folder(os.path.join(self.save_dir, self.model_dir))
         torch.save(self.engine.state_dict("encoder"), os.path.join(save_dir, self.dataset + "_encoder.pkl"))
         torch.save(self.engine.state_dict("decoder"), os.path.join(save_dir, self.dataset + "_decoder.pkl"))
@@ -141,15 +174,33 @@ class CVAE(object):
     def batches(self):
         """(x f32 NCHW in [-1, 1], class indices int32), both on the device."""
         if self.device_preprocess:
-            return DevicePrefetcher(self.trainset_loader, self.batch_size, self.pix_dim, self.device, y_dim=self.y_dim)
+            return DevicePrefetcher(self.trainset_loader, self.local_batch, self.pix_dim, self.device, y_dim=self.y_dim)
         return (self._to_device(imgs, labels) for imgs, labels in self.trainset_loader)
+
+    def train_step(self, x, cls, eps):
+        """One step of models/cvae.py:132-157 on this rank's rows of the batch.  --batch_size (the
+        global batch) divides both losses as in the reference (:137, :139); with N ranks every local
+        loss is scaled by 1/N, so the summed gradients are those of the global-batch mean."""
+        eng = self.engine
+        if self.sync is None:
+            return eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
+        self.sync.begin_step()
+        dec = eng.forward_backward(x, cls, eps, float(self.batch_size), loss_scale=1.0 / self.world)
+        self.sync.finish()
+        eng.adamw_step(self.lr)
+        return dec
+
+    def read_losses(self):
+        """The losses of the whole (global) batch: the mean of the ranks' values."""
+        kl, ll = ddp.allreduce_mean(self.engine.losses[:2]).tolist()
+        return {"VAE": kl + ll, "KL": kl, "LL": ll}
 
     def train(self):
         hist = self.train_hist = {"VAE_loss": [], "KL_loss": [], "LL_loss": [], "per_epoch_time": [], "total_time": []}
         eng = self.engine
         eng.training = True
-        print("training start!!")
-        eps = torch.empty(self.batch_size, self.z_dim, device=self.device)
+        self._print("training start!!")
+        eps = torch.empty(self.local_batch, self.z_dim, device=self.device)
         if self.gan is not None:
             hist.update(D_loss=[], C_loss=[])
             z_p = torch.empty(self.batch_size, self.z_dim, device=self.device)
@@ -161,7 +212,7 @@ class CVAE(object):
             epoch_start = time.time()
             it = -1
             for it, (x, cls) in enumerate(self.batches()):
-                eps.normal_()
+                eps.normal_(generator=self._eps_gen)
                 eng.random_mask()
                 if self.gan is not None:
                     z_p.normal_()
@@ -170,10 +221,10 @@ class CVAE(object):
                     self.gan.gen2.random_mask()
                     self.gan.train_step(x, cls, eps, z_p, y_p, float(self.batch_size), self.lr)
                 else:
-                    eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
+                    self.train_step(x, cls, eps)
                 iters += 1
                 if (it + 1) % self.log_every == 0:
-                    l = eng.read_losses()
+                    l = self.read_losses()
                     if self.gan is not None:
                         gl = self.gan.read_losses()
                         hist["D_loss"].append(gl["D"])
@@ -182,25 +233,28 @@ class CVAE(object):
                     hist["VAE_loss"].append(l["VAE"])
                     hist["KL_loss"].append(l["KL"])
                     hist["LL_loss"].append(l["LL"])
-                    print("Epoch: [%2d] [%4d/%4d] time: %4.4f VAE_loss: %.8f KL_loss: %.8f LL_loss: %.8f" %
-                          (epoch + 1, it + 1, len(self.train_data) // self.batch_size, time.time() - start_time,
-                           l["VAE"], l["KL"], l["LL"]))
+                    self._print("Epoch: [%2d] [%4d/%4d] time: %4.4f VAE_loss: %.8f KL_loss: %.8f LL_loss: %.8f" %
+                                (epoch + 1, it + 1, len(self.train_data) // self.batch_size, time.time() - start_time,
+                                 l["VAE"], l["KL"], l["LL"]))
                 if self.max_iters and iters >= self.max_iters:
                     break
-            samples = self.sample_grid()
-            out_dir = check_folder(os.path.join(self.result_dir, self.model_dir))
-            save_image_grid(samples, self.sample_num, self.y_dim,
-                            os.path.join(out_dir, self.dataset + "_train_{:02d}_{:04d}.png".format(epoch, it + 1)))
+            if self.rank == 0:
+                samples = self.sample_grid()
+                out_dir = check_folder(os.path.join(self.result_dir, self.model_dir))
+                save_image_grid(samples, self.sample_num, self.y_dim,
+                                os.path.join(out_dir, self.dataset + "_train_{:02d}_{:04d}.png".format(epoch, it + 1)))
             if epoch % 10 == 0:
                 self.save()
             hist["per_epoch_time"].append(time.time() - epoch_start)
             if self.max_iters and iters >= self.max_iters:
                 break
         hist["total_time"].append(time.time() - start_time)
-        print("Avg one epoch time: %.2f, total %d epochs time: %.2f" %
-              (float(np.mean(hist["per_epoch_time"])), self.epoch, hist["total_time"][0]))
-        print("Training finish!... save training results")
+        self._print("Avg one epoch time: %.2f, total %d epochs time: %.2f" %
+                    (float(np.mean(hist["per_epoch_time"])), self.epoch, hist["total_time"][0]))
+        self._print("Training finish!... save training results")
         self.save()
+        if self.world > 1:
+            torch.distributed.barrier()                            # the files are on disk before any rank leaves
 
     # ------------------------------------------------------------------ inference
     def sample_grid(self):
@@ -223,7 +277,7 @@ class CVAE(object):
         else:
             x, cls = imgs.to(self.device).float().contiguous(), labels.to(self.device).to(torch.int32)
         eng = self.engine
-        assert x.shape[0] == eng.B, "batch size is fixed by --batch_size"
+        assert x.shape[0] == eng.B, "batch size is fixed by --batch_size (divided by the number of ranks)"
         if eps is None:
             eps = torch.randn(eng.B, self.z_dim, device=self.device)
         was, eng.training = eng.training, False
@@ -245,7 +299,7 @@ class CVAE(object):
         if not ins:
             raise RuntimeError("the dataset is smaller than one batch")
         # rows alternate inputs and reconstructions, one batch per row pair (utils.py:26-33)
-        cols = min(self.batch_size, 16)
+        cols = min(self.local_batch, 16)
         rows = []
         for a, b in zip(ins, outs):
             rows.append(a[:cols])
@@ -253,5 +307,6 @@ class CVAE(object):
         grid = np.concatenate(rows, 0)
         out_dir = check_folder(os.path.join(self.result_dir, self.model_dir))
         path = os.path.join(out_dir, self.dataset + "_test_{:03d}.png".format(iter_num))
-        save_image_grid(grid, len(rows), cols, path)
+        if self.rank == 0:
+            save_image_grid(grid, len(rows), cols, path)
         return path

@@ -1,21 +1,45 @@
-"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce of the
-flat gradient arena over RCCL (torch.distributed backend "nccl" on ROCm), issued on
-a side stream while backward is still producing the remaining gradients.
+"""Data-parallel training: one process per GPU, bucketed all-reduce of the flat gradient
+arena over RCCL (torch.distributed backend "nccl" on ROCm), issued on a side stream while
+backward is still producing the remaining gradients.
 
 Replaces the reference's nn.DataParallel wrapping (models/cvae.py:57-58,
-models/networks.py:307): every rank holds a full replica, BatchNorm statistics stay
-per replica (DataParallel normalises each chunk separately too), each rank scales its
-loss by 1/world so that the SUM all-reduce yields the gradient of the global-batch
-mean loss, and rank 0's BatchNorm running statistics are the ones checkpointed.
+models/networks.py:307): every rank holds a full replica, rank r works on rows
+[r*B/N, (r+1)*B/N) of each global batch, BatchNorm statistics stay per replica (DataParallel
+normalises each chunk separately too), each rank scales its loss by 1/world so that the SUM
+all-reduce yields the gradient of the global-batch mean loss, and rank 0's BatchNorm running
+statistics are the ones checkpointed (DataParallel keeps replica 0's).
 
-The arena is laid out in the order backward finishes gradients (decoder tail ...
-encoder stem), so every stage of backward completes one contiguous range.
+The arena is laid out in the order backward finishes gradients (decoder tail ... encoder
+stem), so every stage of backward completes one contiguous range.  The trainer
+(cvae_gan_amd/cvae.py), bench.py and the tests all exchange through GradSync.
 """
+import os
+
 import torch
 import torch.distributed as dist
+from torch.utils.data import Sampler
 
-# backward stages in completion order and the parameter-key prefixes they finish
-STAGES = ["dec", "enc.head", "enc.blk3", "enc.blk2", "enc.blk1", "enc.blk0", "enc.stem"]
+
+def stages(n_stage=4):
+    """Backward stages in completion order (the names Engine.grad_ready reports)."""
+    return ["dec", "enc.head"] + ["enc.blk%d" % i for i in range(n_stage - 1, -1, -1)] + ["enc.stem"]
+
+
+STAGES = stages(4)
+
+
+def default_groups(n_stage=4):
+    """Three exchanges per step: the decoder's range (travels while the encoder's head and deep
+    blocks run backward), the head + deep blocks (nearly all encoder parameters; travels while the
+    shallow blocks and the stem run, the longest part of the encoder's backward pass), and the
+    rest (the only exposed exchange, ~1.5 MB at 64x64).  The split between deep and shallow
+    blocks is Engine.enc_split = n_stage // 2."""
+    st = stages(n_stage)
+    split = n_stage // 2
+    upper = ["enc.head"] + ["enc.blk%d" % i for i in range(n_stage - 1, split - 1, -1)]
+    lower = ["enc.blk%d" % i for i in range(split - 1, -1, -1)] + ["enc.stem"]
+    assert ["dec"] + upper + lower == st
+    return [["dec"], upper, lower]
 
 
 def stage_of(key, n_stage=4):
@@ -45,21 +69,43 @@ def stage_ranges(arena_order, arena_offsets, arena_numel, n_stage=4):
 
 
 class GradSync:
-    """Bucketed all-reduce of `arena` driven by the engine's grad-ready notifications."""
+    """All-reduce (SUM) of `arena` in contiguous ranges, driven by backward's progress.
 
-    def __init__(self, arena, ranges, stages, bucket_elems=4 << 20, group=None):
+    groups: lists of stage names; the range of a group is exchanged when its last stage reports.
+    groups=None: stages are merged until a range holds at least bucket_elems elements.
+    Stages report either through on_ready(stage) (hook it to Engine.grad_ready for eager launches)
+    or through group_ready(i) (a driver that replays one captured graph per group).
+    With the "nccl" backend the reduction runs on the device on a communication stream; any other
+    backend (gloo: rehearsals with several ranks on one GPU, CPU arenas in tests) reduces a host copy."""
+
+    def __init__(self, arena, ranges, stage_names, bucket_elems=4 << 20, group=None, groups=None):
         self.arena, self.ranges, self.group = arena, ranges, group
-        self.stages = [s for s in stages if s in ranges]
+        self.stages = [s for s in stage_names if s in ranges]
         self.bucket_elems = bucket_elems
+        self.groups = groups
+        self._flush_after = None
+        if groups is not None:
+            assert [s for grp in groups for s in grp] == self.stages, "groups must list every stage in backward order"
+            self._flush_after = {grp[-1] for grp in groups}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = arena.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.device_reduce = self.cuda and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.comm_stream = torch.cuda.Stream(device=arena.device) if self.cuda else None
         self._pending = None
         self._works = []
-        self.launched = []          # (lo, hi) of every bucket of the current step, for tests
+        self.launched = []          # (lo, hi) of every exchange of the current step, for tests
+
+    @classmethod
+    def for_engine(cls, eng, group=None, groups="default", bucket_elems=4 << 20):
+        """The exchange plan of an Engine's gradient arena."""
+        ranges = stage_ranges(eng.arena_order, eng.arena_offsets, eng.arena_numel, eng.n_stage)
+        if groups == "default":
+            groups = default_groups(eng.n_stage)
+        return cls(eng.g_arena, ranges, stages(eng.n_stage), bucket_elems=bucket_elems, group=group, groups=groups)
 
     def begin_step(self):
-        self._pending, self._works, self.launched = None, [], []
+        assert self._pending is None and not self._works, "the previous step was not finished"
+        self.launched = []
 
     def on_ready(self, stage):
         lo, hi = self.ranges[stage]
@@ -68,39 +114,128 @@ class GradSync:
         else:
             assert self._pending[1] == lo, "stages must arrive in arena order"
             self._pending = (self._pending[0], hi)
-        last = stage == self.stages[-1]
-        if last or self._pending[1] - self._pending[0] >= self.bucket_elems:
+        if self._flush_after is not None:
+            flush = stage in self._flush_after
+        else:
+            flush = stage == self.stages[-1] or self._pending[1] - self._pending[0] >= self.bucket_elems
+        if flush:
             self._flush()
+
+    def group_ready(self, i):
+        """Every stage of groups[i] has been enqueued on the current stream."""
+        for stage in self.groups[i]:
+            self.on_ready(stage)
 
     def _flush(self):
         lo, hi = self._pending
         self._pending = None
         self.launched.append((lo, hi))
-        if self.world == 1:
+        if self.world == 1 and not self.device_reduce:
             return
         chunk = self.arena[lo:hi]
-        if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record()                                   # gradients of this bucket are enqueued up to here
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
+        if not self.cuda:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                   # gradients of this range are enqueued up to here
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            if self.device_reduce:
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                self.comm_stream.synchronize()
+                host = chunk.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                chunk.copy_(host)
 
     def finish(self):
-        """Make the compute stream wait for every bucket (call before the optimiser)."""
+        """Make the compute stream wait for every exchange (call before the optimiser)."""
         assert self._pending is None, "a stage never reported its gradients"
         for w in self._works:
             w.wait()
         self._works = []
+        if self.cuda:
+            torch.cuda.current_stream(self.arena.device).wait_stream(self.comm_stream)
 
 
 def broadcast_state(engine, src=0, group=None):
-    """Start every replica from rank `src`'s parameters and BatchNorm buffers."""
+    """Start every replica from rank `src`'s parameters and BatchNorm buffers (the reference's
+    DataParallel replicates module 0's on every forward)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    dist.broadcast(engine.p_arena, src=src, group=group)
+    device_ok = dist.get_backend(group) == "nccl"
+
+    def bcast(t):
+        if device_ok or not t.is_cuda:
+            dist.broadcast(t, src=src, group=group)
+        else:
+            host = t.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.copy_(host)
+
+    bcast(engine.p_arena)
     for t in engine.buffers.values():
-        dist.broadcast(t, src=src, group=group)
+        bcast(t)
     engine.params_changed()
+
+
+def allreduce_mean(t, group=None):
+    """Mean over the ranks of a small device tensor (the two loss scalars, for logging)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "nccl" or not t.is_cuda:
+        out = t.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    else:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        out = host.to(t.device)
+    return out / dist.get_world_size(group)
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the launcher's environment (torchrun); (0, 0, 1) without one."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(device, backend=None):
+    """Join the job's process group; call after torch.cuda.set_device(device) and before any
+    collective.  backend: "nccl" (RCCL, the product path) unless CVG_DDP_BACKEND names another
+    (gloo: several ranks sharing one GPU in rehearsals and tests)."""
+    if dist.is_initialized():
+        return
+    backend = backend or os.environ.get("CVG_DDP_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=device)
+    else:
+        dist.init_process_group(backend=backend)
+
+
+class ShardedBatchSampler(Sampler):
+    """Rank r's rows [r*B/N, (r+1)*B/N) of every global batch of B indices (drop_last, one seeded
+    permutation per epoch shared by all ranks): the rows nn.DataParallel's scatter hands replica r
+    (models/cvae.py:57-58) of the batches DataLoader(shuffle=True, drop_last=True) forms (:47-54)."""
+
+    def __init__(self, n_items, global_batch, rank, world, seed=0, shuffle=True):
+        assert global_batch % world == 0, "--batch_size %d does not split over %d ranks" % (global_batch, world)
+        self.n, self.B, self.rank, self.world, self.seed, self.shuffle = n_items, global_batch, rank, world, seed, shuffle
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.n // self.B
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
+            perm = torch.randperm(self.n, generator=g).tolist()
+        else:
+            perm = list(range(self.n))
+        per = self.B // self.world
+        for b in range(self.n // self.B):
+            lo = b * self.B + self.rank * per
+            yield perm[lo:lo + per]
+        self.epoch += 1

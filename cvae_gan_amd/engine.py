@@ -270,6 +270,15 @@ class Engine:
         self.grad_ready = None      # callable(stage) -> None, see cvae_gan_amd/ddp.py
         self._frozen = False
         self._share, self._own_grads = share, own_grads
+        # position of this engine's dropout stream: the mask is a hash of (element, counter) and the
+        # counter advances by one per step, so streams start 2^32 steps apart per engine of a network
+        # (two generator passes over shared weights must not drop the same units) and 2^40 per seed
+        self._n_shares = 0
+        salt = 0
+        if share is not None:
+            share._n_shares += 1
+            salt = share._n_shares
+        self._dropout_start = ((int(seed) & 0x3FFFFF) << 40) | (salt << 32)
         self.parts, self._extra = parts, OrderedDict(extra_params or {})
         self.stem_input_grad = stem_input_grad
         self.dec = None
@@ -280,7 +289,7 @@ class Engine:
         else:
             self.losses = self._f(4)
             self.step_dev = torch.zeros(1, dtype=torch.long, device=self.device)
-            self.seed_dev = torch.zeros(1, dtype=torch.long, device=self.device)
+            self.seed_dev = torch.full((1,), self._dropout_start, dtype=torch.long, device=self.device)
             self.bc_dev = self._f(2)
         self._build_workspaces()
         if share is not None:        # one optimiser state for all engines of the network
@@ -551,7 +560,7 @@ class Engine:
         self.z_mean, self.z_sigma = self._f(B, self.z), self._f(B, self.z)
         self.losses = self._f(4)          # [kl, ll, -, -]
         self.step_dev = torch.zeros(1, dtype=torch.long, device=self.device)     # AdamW step count
-        self.seed_dev = torch.zeros(1, dtype=torch.long, device=self.device)     # dropout stream position
+        self.seed_dev = torch.full((1,), self._dropout_start, dtype=torch.long, device=self.device)   # dropout stream position
         self.bc_dev = self._f(2)
 
     def _build_workspaces(self):
@@ -705,6 +714,11 @@ class Engine:
     @property
     def enc_split(self):
         return len(self.enc["blocks"]) // 2
+
+    def arena_range(self, prefix):
+        """[lo, hi) of the arena covered by the parameters whose stage (cvae_gan_amd.ddp.stage_of) is `prefix`."""
+        from .ddp import stage_ranges
+        return stage_ranges(self.arena_order, self.arena_offsets, self.arena_numel, self.n_stage)[prefix]
 
     def enc_upper_range(self):
         """[lo, hi) of the gradient arena written by enc_backward(part="upper")."""

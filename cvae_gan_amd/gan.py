@@ -76,7 +76,7 @@ class CVAEGAN:
         kw = dict(dtype=dtype, ngf=ngf, n_stage=n_stage, device=device)
         self.vae = Engine(pix_dim, y_dim, z_dim, batch, seed=seed, state=state, **kw)
         # second pass through the generator (the prior samples): same weights, gradients of its own
-        self.gen2 = Engine(pix_dim, y_dim, z_dim, batch, share=self.vae, own_grads=True, **kw)
+        self.gen2 = Engine(pix_dim, y_dim, z_dim, batch, share=self.vae, own_grads=True, seed=seed, **kw)
         self.D = Critic(pix_dim, 1, features, 3 * batch, seed=seed + 101, **kw)
         self.C = Critic(pix_dim, y_dim, features, 3 * batch, seed=seed + 202, **kw)
         dev = self.vae.device

@@ -106,3 +106,28 @@ def test_stage_ranges_are_contiguous_and_complete():
     assert pos == lay["numel"] == sum((int(torch.Size(lay["shapes"][k]).numel()) + 3) // 4 * 4 for k in lay["order"])
     # parameter count of the reference at 64x64 / 100 classes / z 32 (19,880,467: 11,558,720 encoder + 8,321,747 decoder)
     assert sum(int(torch.Size(lay["shapes"][k]).numel()) for k in lay["order"]) == 19880467
+
+
+def test_exchange_groups_and_batch_shards():
+    from cvae_gan_amd import ddp
+    for n_stage in (4, 5):
+        g = ddp.default_groups(n_stage)
+        assert [s for grp in g for s in grp] == ddp.stages(n_stage) and len(g) == 3
+    assert ddp.default_groups(4)[1] == ["enc.head", "enc.blk3", "enc.blk2"]
+    # rank r takes rows [r*B/N, (r+1)*B/N) of every global batch; the ranks' shards tile the batches of
+    # one shared permutation, and the permutation changes with the epoch
+    world, B, n = 4, 8, 37
+    samplers = [ddp.ShardedBatchSampler(n, B, r, world, seed=3) for r in range(world)]
+    epochs = []
+    for _ in range(2):
+        per_rank = [list(s) for s in samplers]
+        assert all(len(p) == n // B for p in per_rank)
+        batches = [sum((per_rank[r][b] for r in range(world)), []) for b in range(n // B)]
+        flat = sum(batches, [])
+        assert len(set(flat)) == len(flat) == (n // B) * B and all(len(p[0]) == B // world for p in per_rank)
+        epochs.append(flat)
+    assert epochs[0] != epochs[1]
+    g = torch.Generator().manual_seed(3 * 1000003)
+    assert epochs[0] == torch.randperm(n, generator=g).tolist()[:(n // B) * B]
+    with pytest.raises(AssertionError):
+        ddp.ShardedBatchSampler(n, 10, 0, 4)
