@@ -49,6 +49,7 @@ def _load():
             "this package has no fallback compute path." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    f64 = C.c_double
     P = C.POINTER
     sig = {
         "cvg_version": (C.c_int, []),
@@ -89,8 +90,8 @@ def _load():
         "cvg_tail_sum_tanh": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_tanh_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_mse_fwd_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, vp, vp]),
-        "cvg_adamw": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
-        "cvg_adamw_dev": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
+        "cvg_adamw": (C.c_int, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
+        "cvg_adamw_dev": (C.c_int, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, vp, vp, vp]),
         "cvg_dropout_mask_dev": (C.c_int, [vp, i64, vp, vp]),
         "cvg_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
         "cvg_nhwc_to_nchw": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),

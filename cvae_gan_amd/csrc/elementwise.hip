@@ -929,60 +929,61 @@ __global__ void __launch_bounds__(256) mse_finalize(const float* ws, int nblk, f
 }
 
 // ---- AdamW ------------------------------------------------------------------------------------------
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                             float inv_bc1, float inv_sqrt_bc2) {
+// One element of torch.optim.AdamW's update, with the scalars rounded where torch rounds them: every
+// hyper-parameter expression (1 - lr * wd, 1 - beta, lr / bias_correction1, sqrt(bias_correction2)) is
+// evaluated in double on the host (or by adamw_tick) and enters the f32 arithmetic as one float.
+struct AdamScalars {
+    float decay;          // 1 - lr * weight_decay
+    float w1;             // 1 - beta1 (lerp weight of the first moment)
+    float b2, omb2;       // beta2, 1 - beta2
+    float eps;
+};
+__device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, const AdamScalars& k, float step_size,
+                                           float bc2_sqrt) {
+    p *= k.decay;
+    const float d = g - m;                                    // exp_avg.lerp_(grad, 1 - beta1)
+    m = k.w1 < 0.5f ? m + k.w1 * d : g - d * (1.f - k.w1);
+    v = v * k.b2 + k.omb2 * (g * g);                          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + k.eps;
+    p -= step_size * (m / denom);                             // addcdiv_(exp_avg, denom, -step_size)
+}
+__device__ __forceinline__ void adamw_span(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, int64_t n, const AdamScalars& k, float step_size,
+                                           float bc2_sqrt) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 4 <= n) {
         f32x4 pp = *(f32x4*)(p + i), gg = *(const f32x4*)(g + i), mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            pp[j] *= 1.f - lr * wd;
-            mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
-            vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
-            const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
-            pp[j] -= lr * inv_bc1 * (mm[j] / denom);
+            float a = pp[j], b = mm[j], c = vv[j];
+            adamw_elem(a, gg[j], b, c, k, step_size, bc2_sqrt);
+            pp[j] = a; mm[j] = b; vv[j] = c;
         }
         *(f32x4*)(p + i) = pp; *(f32x4*)(m + i) = mm; *(f32x4*)(v + i) = vv;
     } else {
-        for (int64_t k = i; k < n; ++k) {
-            float pp = p[k] * (1.f - lr * wd);
-            const float gg = g[k];
-            const float mm = b1 * m[k] + (1.f - b1) * gg;
-            const float vv = b2 * v[k] + (1.f - b2) * gg * gg;
-            pp -= lr * inv_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
-            p[k] = pp; m[k] = mm; v[k] = vv;
-        }
+        for (int64_t q = i; q < n; ++q) adamw_elem(p[q], g[q], m[q], v[q], k, step_size, bc2_sqrt);
     }
+}
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, const AdamScalars k, float step_size, float bc2_sqrt) {
+    adamw_span(p, g, m, v, n, k, step_size, bc2_sqrt);
 }
 
 // Device-resident step counter: the bias corrections are recomputed on the device so that a
 // captured HIP graph of the step advances AdamW exactly like eager launches do.
-__global__ void adamw_tick(long long* step, float* bc, float b1, float b2) {
+// bc[0] = lr / (1 - beta1^t), bc[1] = sqrt(1 - beta2^t).
+__global__ void adamw_tick(long long* step, float* bc, double lr, double b1, double b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const long long t = *step + 1;
         *step = t;
-        bc[0] = (float)(1.0 / (1.0 - pow((double)b1, (double)t)));
-        bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+        bc[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+        bc[1] = (float)sqrt(1.0 - pow(b2, (double)t));
     }
 }
 __global__ void adamw_kernel_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                 float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                 const float* __restrict__ bc) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    const float inv_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
-    const int cnt = n - i < 4 ? (int)(n - i) : 4;
-    for (int j = 0; j < cnt; ++j) {
-        const int64_t k = i + j;
-        float pp = p[k] * (1.f - lr * wd);
-        const float gg = g[k];
-        const float mm = b1 * m[k] + (1.f - b1) * gg;
-        const float vv = b2 * v[k] + (1.f - b2) * gg * gg;
-        pp -= lr * inv_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
-        p[k] = pp; m[k] = mm; v[k] = vv;
-    }
+                                 float* __restrict__ v, int64_t n, const AdamScalars k, const float* __restrict__ bc) {
+    adamw_span(p, g, m, v, n, k, bc[0], bc[1]);
 }
 __global__ void dropout_mask_dev(uint8_t* mask, int64_t n, const long long* seed_ctr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1252,23 +1253,34 @@ int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, i
     return 0;
 }
 
-int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-              float weight_decay, int32_t step, cvg_stream stream) {
+static AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, double weight_decay) {
+    AdamScalars k;
+    k.decay = (float)(1.0 - lr * weight_decay);
+    k.w1 = (float)(1.0 - beta1);
+    k.b2 = (float)beta2;
+    k.omb2 = (float)(1.0 - beta2);
+    k.eps = (float)eps;
+    return k;
+}
+
+int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+              double weight_decay, int32_t step, cvg_stream stream) {
     CVG_CHECK(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    adamw_kernel<<<grid1(ceil_div(n, 4)), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                                                                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    adamw_kernel<<<grid1(ceil_div(n, 4)), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n,
+                                                                       adam_scalars(lr, beta1, beta2, eps, weight_decay),
+                                                                       (float)(lr / bc1), (float)sqrt(bc2));
     CVG_LAUNCH_CHECK();
     return 0;
 }
 
-int cvg_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int64_t* step_counter, float* bc, cvg_stream stream) {
+int cvg_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int64_t* step_counter, float* bc, cvg_stream stream) {
     CVG_CHECK(p && g && m && v && n > 0 && step_counter && bc, "adamw_dev: bad args");
     hipStream_t s = (hipStream_t)stream;
-    adamw_tick<<<1, 64, 0, s>>>((long long*)step_counter, bc, beta1, beta2);
+    adamw_tick<<<1, 64, 0, s>>>((long long*)step_counter, bc, lr, beta1, beta2);
     CVG_LAUNCH_CHECK();
-    adamw_kernel_dev<<<grid1(ceil_div(n, 4)), 256, 0, s>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc);
+    adamw_kernel_dev<<<grid1(ceil_div(n, 4)), 256, 0, s>>>(p, g, m, v, n, adam_scalars(lr, beta1, beta2, eps, weight_decay), bc);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -289,15 +289,18 @@ int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, i
                     float batch_size, float scale, float* ws, cvg_stream s);
 
 /* torch.optim.AdamW(betas=(0.5, 0.999), eps=1e-8, weight_decay=0.01) over one flat
- * f32 arena (models/cvae.py:67, :157).  step counts from 1.                         */
-int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-              float beta2, float eps, float weight_decay, int32_t step, cvg_stream s);
+ * f32 arena (models/cvae.py:67, :157).  step counts from 1.  The hyper-parameters are doubles, as
+ * the Python floats torch receives: 1 - lr * weight_decay, 1 - beta, lr / (1 - beta1^t) and
+ * sqrt(1 - beta2^t) are evaluated in double and rounded to f32 once, where torch rounds them
+ * (1 - 0.999 evaluated in f32 is off by 1.3e-5 relative, and with it the second moment).   */
+int cvg_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+              double beta2, double eps, double weight_decay, int32_t step, cvg_stream s);
 
 /* The same with the step count kept on the device: *step_counter (int64) is incremented
- * and the bias corrections are written to bc[2] by a one-thread kernel before the update,
- * so a captured HIP graph of the step replays a correct optimiser.                    */
-int cvg_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int64_t* step_counter, float* bc,
+ * and bc[2] = { lr / (1 - beta1^t), sqrt(1 - beta2^t) } is written by a one-thread kernel before
+ * the update, so a captured HIP graph of the step replays a correct optimiser.            */
+int cvg_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t* step_counter, float* bc,
                   cvg_stream s);
 /* Keep mask seeded by a device counter that advances on every call (graph-replay safe). */
 int cvg_dropout_mask_dev(uint8_t* mask, int64_t n, int64_t* seed_counter, cvg_stream s);
