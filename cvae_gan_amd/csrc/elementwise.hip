@@ -1051,6 +1051,47 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     return 0;
 }
 
+// ---- cvg_bn_stats without a workspace argument: the partials live in a static device array ----------
+constexpr int STATIC_MAX_C = 1024, STATIC_MAX_BLK = 512;       // red_blocks() never exceeds 512
+static __device__ __align__(256) float scratch[2 * STATIC_MAX_BLK * STATIC_MAX_C];      // 4 MiB per GPU
+
+// The array's device address, looked up once per device with that device current.  In host code the
+// name `scratch` is only a handle for this lookup: every launch below takes the returned pointer.
+static int static_scratch(float** out) {
+    constexpr int MAX_DEV = 64;
+    static float* ptr[MAX_DEV];
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    CVG_CHECK(e == hipSuccess && dev >= 0 && dev < MAX_DEV, "bn_stats_static: no current device (%s)", hipGetErrorString(e));
+    if (!ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        CVG_CHECK(e == hipSuccess && p, "bn_stats_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+        ptr[dev] = p;
+    }
+    *out = ptr[dev];
+    return 0;
+}
+
+int cvg_bn_stats_static(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats, float* running_mean,
+                        float* running_var, int64_t* nbt, cvg_stream stream) {
+    if (check_rows("bn_stats_static", M, C)) return -1;
+    CVG_CHECK(C <= STATIC_MAX_C, "bn_stats_static: C %d exceeds the static scratch (at most %d channels); use cvg_bn_stats "
+              "with a caller-owned workspace", C, STATIC_MAX_C);
+    CVG_CHECK(x && stats, "bn_stats_static: null");
+    float* ws = nullptr;
+    if (static_scratch(&ws)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    // every partial [which][block][channel] that stats_finalize reads is written by colreduce first, so
+    // nothing left in the array by an earlier call is ever read: no clearing needed
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
+    DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, 1), red_threads(C), 0, s>>>(a));
+    CVG_LAUNCH_CHECK();
+    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
 int cvg_bn_eval_stats(const float* rm, const float* rv, int32_t C, float* stats, cvg_stream stream) {
     CVG_CHECK(rm && rv && stats && C > 0, "bn_eval_stats: bad args");
     eval_stats<<<grid1(C, 128), 128, 0, (hipStream_t)stream>>>(rm, rv, C, stats);

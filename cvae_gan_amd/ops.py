@@ -130,6 +130,11 @@ def bn_stats(x, M, C_, stats, running_mean, running_var, nbt, ws):
                            ptr(ws), stream()))
 
 
+def bn_stats_static(x, M, C_, stats, running_mean, running_var, nbt):
+    """bn_stats without a workspace: the partials go to a static array inside the library (C <= 1024)."""
+    check(lib.cvg_bn_stats_static(ptr(x), dt(x), M, C_, ptr(stats), ptr(running_mean), ptr(running_var), ptr(nbt), stream()))
+
+
 def bn_eval_stats(rm, rv, C_, stats):
     check(lib.cvg_bn_eval_stats(ptr(rm), ptr(rv), C_, ptr(stats), stream()))
 

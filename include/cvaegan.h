@@ -186,6 +186,17 @@ int32_t cvg_bn_stats_blocks(int32_t M, int32_t C);
 int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
                  float* running_mean, float* running_var, int64_t* num_batches_tracked,
                  float* ws, cvg_stream s);
+/* cvg_bn_stats for callers that cannot allocate or pass device scratch memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same kernels, arguments and results as cvg_bn_stats without `ws`: the block partials
+ * go to a 4 MiB array that is part of the library's device image (one copy per GPU the library runs
+ * on, held until the process ends), so the call allocates nothing.  Limit: C <= 1024 (larger C is
+ * rejected with an error, use cvg_bn_stats).  All calls on one GPU share that array: calls whose
+ * kernels may overlap on the same GPU (different streams) race and must be ordered by the caller.
+ * Nothing needs clearing between calls: every partial that is read was written by the same call.  */
+int cvg_bn_stats_static(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        cvg_stream s);
 /* y = LeakyReLU_0.2( gamma * (x - mean) * invstd + beta  [+ res] ).
  * eval mode: pass stats built from the running statistics (cvg_bn_eval_stats).   */
 int cvg_bn_act_fwd(const void* x, const void* res, void* y, int32_t dtype, int32_t M, int32_t C,

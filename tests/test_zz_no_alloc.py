@@ -1,0 +1,53 @@
+"""cvg_bn_stats_static (the entry point that allocates nothing: its block partials live in a static
+device array of the library) against cvg_bn_stats with a caller-owned workspace, through the C ABI.
+Same kernels, so the results must be bit-identical: batch statistics, running statistics and the batch
+counter, on two calls in a row, the second with a smaller input (stale partials of the first call stay
+in the array and must not be read), in both dtypes; and the size limit is an error, not a fault."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(x, M, C):
+    from cvae_gan_amd import ops
+    out = []
+    for static in (False, True):
+        stats = torch.full((2, C), float("nan"), device="cuda")
+        rm = torch.linspace(-1, 1, C, device="cuda")
+        rv = torch.linspace(0.5, 2, C, device="cuda")
+        nbt = torch.full((), 7, dtype=torch.long, device="cuda")
+        if static:
+            ops.bn_stats_static(x, M, C, stats, rm, rv, nbt)
+        else:
+            ws = torch.full((2 * ops.bn_stats_blocks(M, C) * C,), float("nan"), device="cuda")
+            ops.bn_stats(x, M, C, stats, rm, rv, nbt, ws)
+        torch.cuda.synchronize()
+        out.append((stats, rm, rv, nbt))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_static_scratch_equals_workspace_form(dtype):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, C in ((70000, 1024), (333, 64)):          # 512 blocks x 1024 channels fill the array; then a small call
+        x = (torch.randn(M, C, device="cuda", generator=g) * 3 + 1).to(dtype)
+        (s0, m0, v0, n0), (s1, m1, v1, n1) = _both(x, M, C)
+        assert torch.isfinite(s1).all()
+        assert torch.equal(s0, s1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+        assert int(n0) == int(n1) == 8
+        # and against torch: mean / biased variance of the rows
+        xf = x.float()
+        assert torch.allclose(s1[0], xf.mean(0), atol=2e-5, rtol=1e-5)
+        assert torch.allclose(s1[1], 1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5), atol=1e-5, rtol=2e-5)
+
+
+def test_static_scratch_rejects_wide_rows():
+    from cvae_gan_amd import ops
+    x = torch.zeros(16, 1032, device="cuda")
+    stats = torch.zeros(2, 1032, device="cuda")
+    with pytest.raises(ops.CvgError, match="static scratch"):
+        ops.bn_stats_static(x, 16, 1032, stats, None, None, None)
+    ws = torch.zeros(2 * ops.bn_stats_blocks(16, 1032) * 1032, device="cuda")
+    ops.bn_stats(x, 16, 1032, stats, None, None, None, ws)       # the workspace form takes it
+    torch.cuda.synchronize()
