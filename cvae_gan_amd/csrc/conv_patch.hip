@@ -135,7 +135,9 @@ patch_fwd(const PatchFwdArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int tile_y = fdiv(blockIdx.x, t.div_tx), tile_x = blockIdx.x - tile_y * t.tiles_x;
     const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = blockIdx.z * t.TB, n0 = blockIdx.y * BN;
-    const T* __restrict__ xp = (const T*)a.x;
+    // 64-bit base of this workgroup's first image; every offset below is relative to it and fits 32 bits
+    // (at most TB images), so a batch may hold more than 2^31 elements
+    const T* __restrict__ xp = (const T*)a.x + (size_t)b0 * a.x_img_pitch;
 #ifdef EXP_TIMING
     long long tt[5];
     const long long wall0 = wall_clock64();
@@ -179,7 +181,7 @@ patch_fwd(const PatchFwdArgs a) {
             int iy = y0 + py + a.off_y, ix = x0 + px + a.off_x;
             const int b = b0 + tb;
             if (b < a.B && pad_xy(a.pad_mode, a.H, a.W, iy, ix)) {
-                gofs[i] = b * a.x_img_pitch + iy * a.x_row_pitch + ix * a.x_pix_pitch + ci * (16 / ES);
+                gofs[i] = tb * a.x_img_pitch + iy * a.x_row_pitch + ix * a.x_pix_pitch + ci * (16 / ES);
                 pmask |= 1u << i;
             }
         }
@@ -311,7 +313,8 @@ patch_fwd(const PatchFwdArgs a) {
     // tile pixels).  It is set up here, before the staging, so that a residual term (res *
     // LeakyReLU'(gate): the skip branch of a res block's input gradient) can be requested now, as whole
     // 16-byte pieces on consecutive lanes, and arrive while the accumulators go through LDS.
-    T* __restrict__ yp = (T*)a.y;
+    const size_t ybase = (size_t)b0 * a.y_img_pitch;      // res and gate are laid out as y
+    T* __restrict__ yp = (T*)a.y + ybase;
     constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
     constexpr int BMT = WM * WTM;
     constexpr int EPP = 16 / ES;                 // elements per piece
@@ -326,7 +329,7 @@ patch_fwd(const PatchFwdArgs a) {
         const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
         const bool ok = n_out < a.N && q0 < t.npx && b < a.B && oy < a.OH;
         const int step = a.ox_mul * a.y_pix_pitch;
-        int yoff = b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
+        int yoff = tb * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             yo[i] = (ok && ox + i < a.OW) ? yoff + n_out : -1;
@@ -340,13 +343,13 @@ patch_fwd(const PatchFwdArgs a) {
             tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
             const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
             const bool ok = n_out < a.N && q < t.npx && b < a.B && oy < a.OH && ox < a.OW;
-            yo[i] = ok ? b * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
+            yo[i] = ok ? tb * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
         }
     }
     const bool res_mode = a.res != nullptr;      // with a.scale: y = act(scale * conv + shift + res)
     u32x4 rr[PT], gg[PT];
     if (res_mode) {
-        const T* __restrict__ resp = (const T*)a.res;
+        const T* __restrict__ resp = (const T*)a.res + ybase;
         auto fetch = [&](const T* __restrict__ src, u32x4 (&dst)[PT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < PT; ++i) {       // branch-free: pixels that are not stored read element 0
@@ -360,7 +363,7 @@ patch_fwd(const PatchFwdArgs a) {
             }
         };
         fetch(resp, rr);
-        if (a.gate) fetch((const T*)a.gate, gg);
+        if (a.gate) fetch((const T*)a.gate + ybase, gg);
     }
     const bool per_pixel = a.cbias != nullptr;   // the class bias needs the pixel's image
 #pragma unroll
@@ -956,7 +959,8 @@ bool patch_eligible(const cvg_conv_desc* d) {
     if (d->x_pix_pitch != d->Cin && !(d->Cin == CK && d->pad_mode == CVG_PAD_ZERO)) return false;   // overlapping windows: one chunk
     if (!((d->KW == 3 && d->ntaps == 9) || (d->KW == 7 && d->ntaps == 49) || (d->KW == 1 && d->ntaps == 7)))
         return false;                                                                        // instantiated kernels
-    if ((int64_t)d->B * d->x_img_pitch >= (1ll << 31) || (int64_t)d->B * d->y_img_pitch >= (1ll << 31)) return false;
+    // offsets are 32-bit relative to a workgroup's first image: up to 512 images of a tile must fit
+    if (512ll * d->x_img_pitch >= (1ll << 31) || 512ll * d->y_img_pitch >= (1ll << 31)) return false;
     return true;
 }
 
@@ -1170,7 +1174,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     static const bool no_s2 = getenv("CVG_WGRAD_S2_GATHER") != nullptr;      // A/B switch for benchmarking
     if (!no_s2 && d->stride == 2 && d->tstep_y == 1 && d->tstep_x == 1 && d->dtype == CVG_BF16 && d->KW == 3 &&
         d->ntaps == 9 && d->N > 64 && d->Cin % CK == 0 && d->x_pix_pitch == d->Cin && d->pad_mode == CVG_PAD_ZERO &&
-        (int64_t)d->B * d->x_img_pitch < (1ll << 31) && (int64_t)d->B * d->y_img_pitch < (1ll << 31) &&
+        512ll * d->x_img_pitch < (1ll << 31) && 512ll * d->y_img_pitch < (1ll << 31) &&
         choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 592, p.TB, p.TH, p.TW, 2)) {
         // the nine-tap kernel, four waves, one 32-channel chunk per workgroup
         p.KW = 3; p.KH = 3; p.T = 9; p.WN = 4; p.WT = 1; p.BNW = 128;

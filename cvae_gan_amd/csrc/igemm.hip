@@ -108,12 +108,14 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
 
     // ---- loader bookkeeping: this thread fetches 16-byte chunk `cc` of rows r0+32i
     const int cc = tid & 7, r0 = tid >> 3;
-    int riy[AR], rix[AR], rbase[AR];
+    int riy[AR], rix[AR];
+    size_t rbase[AR];                            // element offset of the row's image: may exceed 32 bits
     unsigned rmask = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + r0 + 32 * i;
-        riy[i] = rix[i] = rbase[i] = 0;
+        riy[i] = rix[i] = 0;
+        rbase[i] = 0;
         if (m < g.M) {
             uint32_t b = fdiv(m, g.div_ohw);
             uint32_t rem = m - b * g.OHW;
@@ -121,7 +123,7 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
             uint32_t ox = rem - oy * g.OW;
             riy[i] = oy * g.stride;
             rix[i] = ox * g.stride;
-            rbase[i] = b * g.x_img_pitch;
+            rbase[i] = (size_t)b * g.x_img_pitch;
             rmask |= 1u << i;
         }
     }
@@ -141,7 +143,7 @@ __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zspli
             bool ok = kv && ((rmask >> i) & 1u);
             ok = pad_coord(g, iy, ix) && ok;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *(const u32x4*)(xp + ((size_t)rbase[i] + (size_t)(iy * g.x_row_pitch + ix * g.x_pix_pitch + c)));
+            if (ok) v = *(const u32x4*)(xp + (rbase[i] + (size_t)(iy * g.x_row_pitch + ix * g.x_pix_pitch + c)));
             ra[i] = v;
         }
 #pragma unroll
@@ -540,8 +542,8 @@ int make_geom(const cvg_conv_desc* d, Geom& g) {
     }
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
     CVG_CHECK(M < (1ll << 31), "conv: too many rows");
-    const int64_t x_elems = (int64_t)d->B * d->x_img_pitch;
-    CVG_CHECK(x_elems < (1ll << 31), "conv: gathered tensor too large for 32-bit offsets");
+    // (image bases are 64-bit in every kernel; offsets inside one image are 32-bit, which the descriptor's
+    // int32 pitches guarantee)
     CVG_CHECK((d->x_pix_pitch * elem_size(d->dtype)) % 8 == 0 && d->x_row_pitch % 4 == 0 && d->x_img_pitch % 4 == 0,
               "conv: pitches must keep 8-byte alignment");
     if (d->pad_mode == CVG_PAD_REFLECT) {
@@ -753,7 +755,6 @@ int cvg_conv_wgrad_strided(const cvg_conv_desc* d, const void* x, const void* dy
     PatchWgradPlan wp;
     patch_wgrad_plan(d, wp);
     CVG_CHECK(patch_enabled() && wp.ok, "conv_wgrad_strided: only the patch-staged kernels read strided dY");
-    CVG_CHECK((int64_t)d->B * d->y_img_pitch < (1ll << 31), "conv_wgrad_strided: dY too large for 32-bit offsets");
     CVG_CHECK(ws_bytes >= wp.ws_bytes, "conv_wgrad_strided: workspace too small");
     return patch_wgrad_launch(d, wp, x, dy, d->y_pix_pitch, d->y_img_pitch, d->y_row_pitch, d->N, map, grad, accumulate,
                               (float*)ws, (hipStream_t)stream);

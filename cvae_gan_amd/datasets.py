@@ -74,6 +74,19 @@ class SyntheticBodyMaps(Dataset):
         return img, y
 
 
+def mnist_to_input(gray, pix_dim=32):
+    """MNIST-shaped batches for the reference's networks: gray [B,1,S,S] in [0, 1] -> [B,3,P,P] in [-1, 1].
+    The networks take 3-channel images (models/networks.py:80) whose side is a multiple of 16
+    (models/networks.py:179, :136), so 28 x 28 digits are zero-padded (black) to 32 x 32 around the centre,
+    normalised as datasets.py:14-18 does ((v - .5) / .5) and replicated to three channels."""
+    B, _, S, _ = gray.shape
+    assert S <= pix_dim and (pix_dim - S) % 2 == 0
+    lo = (pix_dim - S) // 2
+    out = torch.zeros(B, 1, pix_dim, pix_dim, dtype=torch.float32)
+    out[:, :, lo:lo + S, lo:lo + S] = gray.float()
+    return ((out - 0.5) / 0.5).expand(B, 3, pix_dim, pix_dim).contiguous()
+
+
 def make_dataset(data_dir, dataset, pix_dim, cls_num, max_size=-1, synthetic_size=2048, raw=False):
     """The reference's dataset when its files exist, the synthetic stand-in otherwise.
     raw=True: items are (uint8 HWC image, class index) for DevicePrefetcher."""

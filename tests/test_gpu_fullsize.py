@@ -121,6 +121,50 @@ def test_p128_eval_paths_match_oracle(dtype):
         assert cosine(full, full_ref) >= 0.998 and cosine(dec, dec_ref) >= 0.998, (cosine(full, full_ref), cosine(dec, dec_ref))
 
 
+def test_c5_batch_1024_eval_forward():
+    """BASELINE configuration 5 in one call: eval-mode encoder + decoder forward at 128 x 128, batch 1024,
+    bf16.  The decoder's last up-sampled, reflection-padded tensor holds 1024 x 130 x 130 x 128 = 2.2e9
+    elements, more than 32-bit element offsets reach.  In eval mode no operation couples the images of a
+    batch, so rows of the big batch must agree with the same images run as a batch of 4 (first rows, and
+    the last rows, which sit beyond the 2^31st element of that tensor), up to the summation order of the
+    Linear layers, whose split depends on the batch: cosine >= 0.9995, and both within cosine 0.998 of the
+    f32 oracle.  Weights and running statistics as in test_p128_eval_paths_match_oracle."""
+    from cvae_gan_amd.engine import Engine
+    from oracle import ref_cpu as O
+    from parity import synthetic_inputs, synthetic_state, cosine
+    B, PP = 1024, 128
+    x, labels, eps, _ = synthetic_inputs(PP, Y, Z, B, 41)
+    e, d = synthetic_state(PP, Y, Z, 13)
+    rows = torch.cat([torch.arange(4), torch.arange(B - 4, B)])
+    new_stats = {}
+    with torch.no_grad():
+        O.encoder_forward(e, x[rows], O.label_planes(labels[rows], Y, PP), True, new_stats)
+        for k, v in new_stats.items():
+            if not k.endswith("tracked"):
+                e[k] = (v - (1 - O.BN_MOMENTUM) * e[k]) / O.BN_MOMENTUM
+        ref, _, _, _ = O.cvae_forward(e, d, x[rows], labels[rows], eps[rows], None, Y, train=False)
+    state = OrderedDict(e)
+    state.update(d)
+    big = Engine(PP, Y, Z, B, dtype=torch.bfloat16, state=state)
+    big.training = False
+    out = big.reconstruct(x.cuda(), labels.int().cuda(), eps.cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    got = out[rows.cuda()].cpu()
+    small = Engine(PP, Y, Z, 8, dtype=torch.bfloat16, share=big)
+    small.training = False
+    same = small.reconstruct(x[rows].cuda(), labels[rows].int().cuda(), eps[rows].cuda()).cpu()
+    print("c5 B=1024: cos(big, small) %.6f  cos(big, oracle) %.6f  max|big - small| %.3e" % (
+        cosine(got, same), cosine(got, ref), float((got - same).abs().max())))
+    assert cosine(got[:4], same[:4]) >= 0.9995 and cosine(got[4:], same[4:]) >= 0.9995
+    assert cosine(got[:4], ref[:4]) >= 0.998 and cosine(got[4:], ref[4:]) >= 0.998
+    dec = big.decode(eps.cuda(), torch.nn.functional.one_hot(labels, Y).float().cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(dec).all() and float(dec.abs().max()) <= 1.0
+    del big, small
+    torch.cuda.empty_cache()
+
+
 def test_c4_full_batch_bf16_is_deterministic():
     """128 x 128 at the configuration's per-GPU batch of 64, bf16, four and five stages: finite,
     non-zero and run-to-run bit-identical gradients and losses."""

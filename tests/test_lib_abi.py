@@ -58,11 +58,14 @@ def _rejected(d, needle):
 
 
 def test_size_and_padding_limits_are_rejected_without_a_gpu():
-    """The kernels index the gathered tensor with 32-bit element offsets and mirror a coordinate
-    once: a descriptor beyond either limit must fail in validation, never reach a launch."""
-    # 640 images of 130 x 130 x 256 (a padded 128 x 128 map) = 2.77e9 elements
+    """The kernels mirror a coordinate once and need power-of-two channel counts per tap: a descriptor
+    beyond a limit must fail in validation, never reach a launch.  (Batches beyond 2^31 elements are
+    fine: image bases are 64-bit, tests/test_gpu_fullsize.py runs one.)"""
+    # 640 images of 130 x 130 x 256 (a padded 128 x 128 map) = 2.77e9 elements: valid geometry, fails only
+    # on the null tensors
     _rejected(_desc(B=640, H=130, W=130, Cin=256, OH=128, OW=128, x_pix_pitch=256, x_row_pitch=130 * 256,
-                    x_img_pitch=130 * 130 * 256), b"32-bit")
+                    x_img_pitch=130 * 130 * 256, w_ld=9 * 256, y_pix_pitch=16, y_row_pitch=128 * 16,
+                    y_img_pitch=128 * 128 * 16), b"null tensor")
     # reflection by 3 into a 2-pixel-wide tensor needs two reflections
     _rejected(_desc(H=2, W=2, OH=2, OW=2, KW=7, ntaps=49, off_y=-3, off_x=-3, pad_mode=1, x_row_pitch=2 * 16,
                     x_img_pitch=4 * 16), b"reflection")

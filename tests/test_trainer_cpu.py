@@ -66,3 +66,13 @@ def test_model_dir_format():
     obj = CVAE.__new__(CVAE)
     obj.dataset, obj.pix_dim, obj.batch_size, obj.z_dim = "PoseUnit-stretch", 64, 550, 32
     assert obj.model_dir == "VAE_data_PoseUnit-stretch_pix_64_batch_550_embed_32"   # test.sh's --pkl path
+
+
+def test_mnist_shaped_inputs():
+    """BASELINE configuration 1's plumbing: 28 x 28 gray digits -> 32 x 32 x 3 in [-1, 1], black border."""
+    g = torch.rand(5, 1, 28, 28)
+    x = D.mnist_to_input(g, 32)
+    assert x.shape == (5, 3, 32, 32) and float(x.min()) >= -1 and float(x.max()) <= 1
+    assert torch.equal(x[:, 0], x[:, 1]) and torch.equal(x[:, 0], x[:, 2])
+    assert torch.all(x[:, :, :2] == -1) and torch.all(x[:, :, :, -2:] == -1)
+    assert torch.allclose(x[:, 0, 2:30, 2:30], (g[:, 0] - 0.5) / 0.5)
