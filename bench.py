@@ -79,12 +79,14 @@ class KernelTimer:
 
         # HBM-bound passes, algorithmic bytes: BatchNorm forward = statistics (1 read) + apply (1 read,
         # + the residual, 1 write); backward = two passes over dy, x (and y where the gate is read from it) + 1 write
-        def bn(x, res, y, M, C, stats, prefix):
+        def bn(x, res, y, M, C, stats, prefix, partial_rows=0):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            self._bn(x, res, y, M, C, stats, prefix)
+            self._bn(x, res, y, M, C, stats, prefix, partial_rows=partial_rows)
             b.record()
-            self.hbm.append(("batchnorm+lrelu forward (statistics, apply)", M * C * es * (3 + (res is not None)), a, b))
+            # with partial_rows the producing convolution has already summed x: no statistics read
+            passes = (2 if partial_rows else 3) + (res is not None)
+            self.hbm.append(("batchnorm+lrelu forward (statistics, apply)", M * C * es * passes, a, b))
 
         def bn_bwd(dy, y, x, dx, M, C, stats, prefix, **kw):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -70,6 +70,9 @@ def _load():
         "cvg_pack_image": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "cvg_bn_stats_blocks": (i32, [i32, i32]),
         "cvg_bn_stats": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "cvg_conv_stats_partials": (i32, [P(ConvDesc)]),
+        "cvg_conv_fwd_stats": (C.c_int, [P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+        "cvg_bn_stats_finalize": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
         "cvg_bn_stats_static": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
         "cvg_bn_act_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
         "cvg_bn_eval_stats": (C.c_int, [vp, vp, i32, vp, vp]),

@@ -20,7 +20,10 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p);
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
                      const void* gate, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr,
-                     int act = 0);
+                     int act = 0, float* stat_ws = nullptr);
+// stat_ws: f32 [2][tiles][N] with tiles = patch_stat_tiles(plan): per pixel tile, the column sums and sums of
+// squares of the stored output (BatchNorm batch statistics without a pass over the output).
+inline int patch_stat_tiles(const PatchPlan& p) { return p.tiles_y * p.tiles_x * p.groups; }
 // Weights in MFMA-fragment order: [n/32][chunk][tap][k16 half][lane][8].
 int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap* map, const float* canonical,
                       void* packed, hipStream_t s);

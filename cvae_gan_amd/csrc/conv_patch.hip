@@ -29,6 +29,7 @@ struct PatchFwdArgs {
     const void* x; const void* wf; void* y;
     const float* bias; const float* cbias; const int* labels; const void* res; const void* gate;
     const float* scale; const float* shift; int act;     // eval-mode BatchNorm + LeakyReLU in the epilogue
+    float* stat_ws;                                       // per-tile column sums of the stored output, or null
     int B, H, W, Cin, x_img_pitch, x_row_pitch, x_pix_pitch;
     int off_y, off_x, pad_mode, KW, T;
     int OH, OW, N;
@@ -101,6 +102,18 @@ template <> __device__ __forceinline__ u32x4 add_gated<bf16>(u32x4 v, u32x4 r, u
         o[j] = (__bf16)f;
     }
     return __builtin_bit_cast(u32x4, o);
+}
+
+// values of one staged 16-byte piece as floats (8 for bf16, 4 for f32)
+template <typename T> __device__ __forceinline__ void piece_values(u32x4 v, float (&f)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ void piece_values<float>(u32x4 v, float (&f)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = __uint_as_float(v[j]);
+}
+template <> __device__ __forceinline__ void piece_values<bf16>(u32x4 v, float (&f)[8]) {
+    const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)b[j];
 }
 
 // ======================================================================================
@@ -425,13 +438,53 @@ patch_fwd(const PatchFwdArgs a) {
     // Second half: whole pixel rows leave LDS, 16 bytes per lane, consecutive lanes on consecutive
     // addresses; the residual term joins here.
     const bool gated = a.gate != nullptr;
+    const bool want_stats = a.stat_ws != nullptr;     // BatchNorm batch statistics of this output: sum, sum of squares
+    float st_s[EPP], st_q[EPP];
+#pragma unroll
+    for (int j = 0; j < EPP; ++j) st_s[j] = st_q[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         if (yo[i] < 0) continue;
         u32x4 v = *(const u32x4*)(smem + (q0 + i) * OP + pc * 16);
         if (res_mode) v = add_gated<T>(v, rr[i], gg[i], gated, a.scale && a.act);
+        if (want_stats) {                             // of the values as stored (rounded to T), in pixel order
+            float f[EPP];
+            piece_values<T>(v, f);
+#pragma unroll
+            for (int j = 0; j < EPP; ++j) { st_s[j] += f[j]; st_q[j] += f[j] * f[j]; }
+        }
         if (whole) *(u32x4*)(yp + yo[i]) = v;
         else *(unsigned long long*)(yp + yo[i]) = ((unsigned long long)v[1] << 32) | v[0];
+    }
+    if (want_stats) {
+        // Threads with equal pc hold sums of the same EPP channels: inside a wave they sit PPR lanes apart
+        // (butterfly, both partners compute the same sum), the waves meet in LDS and are added in wave
+        // order, so a tile's partial does not depend on scheduling.  One partial row per pixel tile:
+        // ws[which][tile][channel], tile = blockIdx.x + gridDim.x * blockIdx.z.
+        __shared__ float stat_sm[2][NT / 64][BN];
+#pragma unroll
+        for (int o = PPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < EPP; ++j) {
+                st_s[j] += __shfl_xor(st_s[j], o, 64);
+                st_q[j] += __shfl_xor(st_q[j], o, 64);
+            }
+        if (lane < PPR) {
+#pragma unroll
+            for (int j = 0; j < EPP; ++j) {
+                stat_sm[0][wave][lane * EPP + j] = st_s[j];
+                stat_sm[1][wave][lane * EPP + j] = st_q[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) { s0 += stat_sm[0][w][tid]; s1 += stat_sm[1][w][tid]; }
+            const size_t nblk = (size_t)gridDim.x * gridDim.z, tile = blockIdx.x + (size_t)gridDim.x * blockIdx.z;
+            a.stat_ws[tile * a.N + n0 + tid] = s0;
+            a.stat_ws[(nblk + tile) * a.N + n0 + tid] = s1;
+        }
     }
 #ifdef EXP_TIMING
     finish();
@@ -1107,9 +1160,9 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
 
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
-                     const void* gate, hipStream_t s, const float* scale, const float* shift, int act) {
+                     const void* gate, hipStream_t s, const float* scale, const float* shift, int act, float* stat_ws) {
     PatchFwdArgs a;
-    a.scale = scale; a.shift = shift; a.act = act;
+    a.scale = scale; a.shift = shift; a.act = act; a.stat_ws = stat_ws;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels; a.res = res; a.gate = gate;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch; a.x_pix_pitch = d->x_pix_pitch;

@@ -1051,6 +1051,15 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     return 0;
 }
 
+int cvg_bn_stats_finalize(const float* partials, int32_t nblk, int32_t M, int32_t C, float* stats, float* running_mean,
+                          float* running_var, int64_t* nbt, cvg_stream stream) {
+    CVG_CHECK(partials && stats && nblk > 0 && M > 0 && C > 0, "bn_stats_finalize: bad args");
+    stats_finalize<<<grid1(C, FIN_CH), 256, 0, (hipStream_t)stream>>>(partials, nblk, M, C, stats, running_mean, running_var,
+                                                                      (long long*)nbt);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- cvg_bn_stats without a workspace argument: the partials live in a static device array ----------
 constexpr int STATIC_MAX_C = 1024, STATIC_MAX_BLK = 512;       // red_blocks() never exceeds 512
 static __device__ __align__(256) float scratch[2 * STATIC_MAX_BLK * STATIC_MAX_C];      // 4 MiB per GPU

@@ -698,6 +698,26 @@ int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, 
     return d->dtype == CVG_BF16 ? launch_fwd<bf16>(d, a, s) : launch_fwd<float>(d, a, s);
 }
 
+int32_t cvg_conv_stats_partials(const cvg_conv_desc* d) {
+    PatchPlan pp;
+    pp.ok = 0;
+    if (patch_enabled()) patch_fwd_plan(d, pp);
+    return pp.ok ? patch_stat_tiles(pp) : 0;
+}
+
+int cvg_conv_fwd_stats(const cvg_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                       const float* cbias, const int32_t* labels, float* partials, cvg_stream stream) {
+    CVG_CHECK(d && x && w && y && partials, "conv_fwd_stats: null argument");
+    CVG_CHECK(!cbias || labels, "conv_fwd_stats: cbias needs labels");
+    CVG_CHECK(d->N > 0 && d->N % 4 == 0, "conv_fwd_stats: N %d must be a multiple of 4", d->N);
+    PatchPlan pp;
+    pp.ok = 0;
+    if (patch_enabled()) patch_fwd_plan(d, pp);
+    CVG_CHECK(pp.ok, "conv_fwd_stats: this layer runs on the gather kernel; use cvg_conv_fwd + cvg_bn_stats");
+    return patch_fwd_launch(d, pp, x, w, y, bias, cbias, labels, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0,
+                            partials);
+}
+
 int cvg_conv_bn_act_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                         const float* cbias, const int32_t* labels, const float* scale, const float* shift,
                         const void* res, cvg_stream stream) {

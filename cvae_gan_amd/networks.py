@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import torch_ops
 from .engine import Engine, param_shapes, init_state, is_buffer, EP, DP
 
 
@@ -120,38 +120,29 @@ class _Pair:
 
 
 class _EncFn(torch.autograd.Function):
+    """ResNetEncoder.forward and its backward through torch.ops.cvaegan (cvae_gan_amd/torch_ops.py)."""
+
     @staticmethod
     def forward(ctx, eng, keys, x, labels, *params):
-        eng.params_changed()                 # an outside optimiser may have stepped
-        h = eng.enc_forward(x.contiguous().float(), labels)
-        ctx.eng, ctx.keys = eng, keys
-        return h.float()
+        ctx.eng, ctx.keys, ctx.handle = eng, keys, torch_ops.register_engine(eng)
+        return torch.ops.cvaegan.encoder_forward(ctx.handle, x, labels)
 
     @staticmethod
     def backward(ctx, dh):
-        eng = ctx.eng
-        ops.cast(dh.contiguous().float(), eng.enc["dh"], dh.numel())
-        eng.enc_backward(eng.enc["dh"])
-        return (None, None, None, None) + tuple(eng.grads[k] for k in ctx.keys)
+        torch.ops.cvaegan.encoder_backward(ctx.handle, dh)
+        return (None, None, None, None) + tuple(ctx.eng.grads[k] for k in ctx.keys)
 
 
 class _DecFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, keys, z, y_vec, *params):
-        eng.params_changed()
-        zin = eng.set_decoder_input(z.float(), y_vec.float())
-        if eng.training:
-            eng.random_mask()
-        dec = eng.dec_forward(zin, eng.dec["mask"])
-        ctx.eng, ctx.keys = eng, keys
-        return dec.clone()
+        ctx.eng, ctx.keys, ctx.handle = eng, keys, torch_ops.register_engine(eng)
+        return torch.ops.cvaegan.decoder_forward(ctx.handle, z, y_vec, bool(eng.training))
 
     @staticmethod
     def backward(ctx, d_dec):
-        eng = ctx.eng
-        dzin = eng.dec_backward(d_dec.contiguous().float(), eng.dec["mask"])
-        dz = dzin[:, :eng.z].float()
-        return (None, None, dz, None) + tuple(eng.grads[k] for k in ctx.keys)
+        dz = torch.ops.cvaegan.decoder_backward(ctx.handle, d_dec)
+        return (None, None, dz, None) + tuple(ctx.eng.grads[k] for k in ctx.keys)
 
 
 class encoder(_Half):

@@ -130,6 +130,21 @@ def bn_stats(x, M, C_, stats, running_mean, running_var, nbt, ws):
                            ptr(ws), stream()))
 
 
+def conv_stats_partials(desc):
+    """Partial rows cvg_conv_fwd_stats writes for this layer (0: the layer runs on the gather kernel)."""
+    return int(lib.cvg_conv_stats_partials(C.byref(desc)))
+
+
+def conv_fwd_stats(desc, x, w, y, partials, bias=None, cbias=None, labels=None):
+    check(lib.cvg_conv_fwd_stats(C.byref(desc), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(cbias), ptr(labels),
+                                 ptr(partials), stream()))
+
+
+def bn_stats_finalize(partials, nblk, M, C_, stats, running_mean, running_var, nbt):
+    check(lib.cvg_bn_stats_finalize(ptr(partials), nblk, M, C_, ptr(stats), ptr(running_mean), ptr(running_var),
+                                    ptr(nbt), stream()))
+
+
 def bn_stats_static(x, M, C_, stats, running_mean, running_var, nbt):
     """bn_stats without a workspace: the partials go to a static array inside the library (C <= 1024)."""
     check(lib.cvg_bn_stats_static(ptr(x), dt(x), M, C_, ptr(stats), ptr(running_mean), ptr(running_var), ptr(nbt), stream()))

@@ -186,6 +186,18 @@ int32_t cvg_bn_stats_blocks(int32_t M, int32_t C);
 int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
                  float* running_mean, float* running_var, int64_t* num_batches_tracked,
                  float* ws, cvg_stream s);
+/* The same statistics without the pass over x: a convolution that the patch kernel takes can emit, from
+ * its epilogue, one row of column sums and sums of squares of the values it stores per pixel tile
+ * (cvg_conv_fwd_stats: partials f32 [2][tiles][N], tiles = cvg_conv_stats_partials(d), 0 = this layer
+ * runs on the gather kernel); cvg_bn_stats_finalize turns such rows (or cvg_bn_stats's workspace) into
+ * mean / invstd and the running-statistics update.  Fixed summation orders throughout.  Replaces
+ * nn.Conv2d + the statistics half of nn.BatchNorm2d at models/networks.py:173-174, :234-238.       */
+int32_t cvg_conv_stats_partials(const cvg_conv_desc* d);
+int cvg_conv_fwd_stats(const cvg_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                       const float* cbias, const int32_t* labels, float* partials, cvg_stream s);
+int cvg_bn_stats_finalize(const float* partials, int32_t nblk, int32_t M, int32_t C, float* stats,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          cvg_stream s);
 /* cvg_bn_stats for callers that cannot allocate or pass device scratch memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
  * reference.  Same kernels, arguments and results as cvg_bn_stats without `ws`: the block partials

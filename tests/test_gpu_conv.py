@@ -312,3 +312,49 @@ def test_batchnorm_leakyrelu_forward_backward(dtype, M, C, with_res):
     if dtype == torch.float32:
         for a, b in zip((dxd, dg, db), outs[0]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,cin,cout", [(5, 20, 32, 64), (3, 16, 64, 128), (2, 12, 32, 40), (7, 9, 128, 256)])
+def test_conv_epilogue_statistics(dtype, B, H, cin, cout):
+    """cvg_conv_fwd_stats + cvg_bn_stats_finalize: the stored output equals cvg_conv_fwd's bit for bit, and
+    the batch statistics (mean, 1/sqrt(var + eps), running statistics, batch counter) equal those of
+    cvg_bn_stats over that output up to f32 summation order (ragged tiles, several channel tiles)."""
+    ops, _desc, _wmap = _mods()
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g).cuda()
+    d = _desc(dtype, B, H, H, cin, H, H, cout, 3, 9, off=(-1, -1))
+    wm = _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9)
+    nblk = ops.conv_stats_partials(d)
+    assert nblk > 0 and ops.conv_fwd_kernel(d).startswith("patch_fwd")
+    xr, wp = to_rows(x, dtype), pack(ops, wm, w, d, dtype)
+    M = B * H * H
+    y0 = torch.zeros(M, cout, dtype=dtype, device="cuda")
+    y1 = torch.zeros_like(y0)
+    ops.conv_fwd(d, xr, wp, y0, bias=bias, ws=ws_for(ops, d))
+    part = torch.full((2 * nblk * cout,), float("nan"), device="cuda")
+    ops.conv_fwd_stats(d, xr, wp, y1, part, bias=bias)
+    out = []
+    for fused in (False, True):
+        stats = torch.zeros(2, cout, device="cuda")
+        rm, rv = torch.full((cout,), 0.3, device="cuda"), torch.full((cout,), 1.7, device="cuda")
+        nbt = torch.full((), 4, dtype=torch.long, device="cuda")
+        if fused:
+            ops.bn_stats_finalize(part, nblk, M, cout, stats, rm, rv, nbt)
+        else:
+            ws = torch.zeros(2 * ops.bn_stats_blocks(M, cout) * cout, device="cuda")
+            ops.bn_stats(y0, M, cout, stats, rm, rv, nbt, ws)
+        torch.cuda.synchronize()
+        out.append((stats, rm, rv, int(nbt)))
+    assert torch.equal(y0, y1)
+    assert torch.isfinite(part).all()
+    (s0, m0, v0, n0), (s1, m1, v1, n1) = out
+    assert n0 == n1 == 5
+    assert torch.allclose(s0[0], s1[0], atol=1e-5, rtol=1e-5) and torch.allclose(s0[1], s1[1], rtol=1e-5)
+    assert torch.allclose(m0, m1, atol=1e-6, rtol=1e-5) and torch.allclose(v0, v1, rtol=1e-5)
+    # the gather kernel's layers report that they have no such epilogue
+    d2 = _desc(dtype, B, H, H, cin, H // 2, H // 2, cout, 3, 9, stride=2, off=(-1, -1)) if H % 2 == 0 else None
+    if d2 is not None:
+        assert ops.conv_stats_partials(d2) == 0

@@ -91,3 +91,34 @@ def test_reference_style_training_loop(name):
         samples = dec(zs[:3], ys[:3])
     assert samples.shape == (3, 3, c.P, c.P) and bool(torch.isfinite(samples).all())
     assert float(samples.abs().max()) <= 1.0
+
+
+def test_module_surface_runs_through_torch_custom_ops(monkeypatch):
+    """encoder / decoder forward and backward go through torch.ops.cvaegan.* (cvae_gan_amd/torch_ops.py),
+    and a tensor-only operator gives what the direct binding gives."""
+    from cvae_gan_amd import torch_ops, ops
+    c = Case("tiny_p16_ngf8")
+    N, enc, dec, model = make(c)
+    calls = []
+    real = torch_ops._engine
+    monkeypatch.setattr(torch_ops, "_engine", lambda h: (calls.append(h), real(h))[1])
+    x, labels, eps, mask = c.inputs(0)
+    yvec = torch.zeros(c.B, c.y)
+    yvec[torch.arange(c.B), labels] = 1
+    model.train()
+    out = model(x.cuda(), labels.cuda(), yvec.cuda())
+    out.square().mean().backward()
+    torch.cuda.synchronize()
+    assert len(calls) == 4 and len(set(calls)) == 1          # enc fwd, dec fwd, dec bwd, enc bwd on one engine
+    for name in torch_ops.OPS:
+        assert hasattr(torch.ops.cvaegan, name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    p0 = torch.randn(1001, device="cuda", generator=g)
+    grad = torch.randn(1001, device="cuda", generator=g)
+    a, b = [p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)], [p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)]
+    torch.ops.cvaegan.adamw(a[0], grad, a[1], a[2], 1e-3, 0.5, 0.999, 1e-8, 0.01, 1)
+    ops.adamw(b[0], grad, b[1], b[2], 1001, 1e-3, 0.5, 0.999, 1e-8, 0.01, 1)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(a, b)) and not torch.equal(a[0], p0)
+    with pytest.raises(NotImplementedError):                  # no CPU implementation: no silent other path
+        torch.ops.cvaegan.adamw(p0.cpu(), grad.cpu(), p0.cpu(), p0.cpu(), 1e-3, 0.5, 0.999, 1e-8, 0.01, 1)
