@@ -35,7 +35,7 @@ struct PatchFwdArgs {
     int OH, OW, N;
     int y_img_pitch, y_row_pitch, y_pix_pitch, oy_mul, oy_off, ox_mul, ox_off;
     int nchunks, patch_px, patch_bytes;
-    int lane_perm;                          // tile rows are 16 pixels wide: use lane_pixel()
+    int lane_perm;                          // lane groups of an LDS read take consecutive pixels: lane_pixel()
     int row_fast;                           // tile rows hold a multiple of the epilogue's pixels per thread
 #ifdef EXP_TIMING
     long long* dbg;
@@ -1174,7 +1174,13 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
     a.nchunks = p.nchunks; a.patch_px = p.patch_px;
     a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
-    a.lane_perm = (p.TW % 16 == 0) ? 1 : 0;
+    // Each ds_read_b128 lane group then reads 16 CONSECUTIVE tile pixels.  With 16-pixel tile rows that is
+    // one row (conflict-free); with other widths the 16 pixels cross a row boundary and two of them collide
+    // (2 LDS cycles instead of 1), where the natural lane order spreads a group over 28 consecutive pixels
+    // and collides up to three ways: measured -5..-7 % on the 8 x 8 layers and on the decoder's
+    // input-gradient layers (10-, 18- and 66-pixel-wide grids), none slower.  CVG_PATCH_PERM=0: as before.
+    static const char* perm = getenv("CVG_PATCH_PERM");
+    a.lane_perm = (perm && perm[0] == '0') ? ((p.TW % 16 == 0) ? 1 : 0) : 1;
     {   // pixels per thread in the store phase: BM * (BN * es / 16) / threads
         static const char* wide8 = getenv("CVG_PATCH_WIDE");
         const bool four = wide8 && wide8[0] == '1';
