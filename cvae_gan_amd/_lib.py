@@ -103,6 +103,9 @@ def _load():
         "cvg_gan_d_head": (C.c_int, [vp, i32, i32, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
         "cvg_gan_c_head": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
         "cvg_gan_feature_match": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
+        "cvg_gan_class_feature_match": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp,
+                                                   vp, vp]),
+        "cvg_gan_pair_feature_match": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
         "cvg_axpy_f32": (C.c_int, [vp, vp, f32, i64, vp]),
     }
     for name, (res, args) in sig.items():

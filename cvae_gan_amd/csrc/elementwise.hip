@@ -394,6 +394,74 @@ __global__ void __launch_bounds__(1024) feature_match(const T* __restrict__ h, i
     }
 }
 
+// Per-class feature centres (the paper's L_GC): block c handles class c.  The centre of the REAL rows of
+// class c is a moving average kept across steps (a constant target); the rows [f0, f1) (generated images)
+// of class c are pulled towards it as a group: loss_c = 1/2 |mean_fake_c - centre_c|^2, and the gradient
+// (mean_fake_c - centre_c) * gscale / n_fake_c is ADDED to those rows of dh.  Classes without generated
+// rows, or whose centre has never been seen, contribute nothing.
+template <typename T>
+__global__ void __launch_bounds__(256) class_feature_match(const T* __restrict__ h, int ld, int F, const int* __restrict__ labels_r,
+                                                           const int* __restrict__ labels_f, int r0, int r1, int f0, int f1,
+                                                           float* __restrict__ centre, int* __restrict__ seen, float momentum,
+                                                           float gscale, float* __restrict__ loss_c, T* __restrict__ dh) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    int nr = 0, nf = 0;
+    for (int r = r0; r < r1; ++r) nr += labels_r[r - r0] == c;
+    for (int r = f0; r < f1; ++r) nf += labels_f[r - f0] == c;
+    const bool was_seen = seen[c] != 0;
+    float part = 0.f;
+    for (int j = tid; j < F; j += 256) {
+        float m = centre[(size_t)c * F + j];
+        if (nr > 0) {
+            float sr = 0.f;
+            for (int r = r0; r < r1; ++r)
+                if (labels_r[r - r0] == c) sr += to_f32(h[(size_t)r * ld + j]);
+            sr /= (float)nr;
+            m = was_seen ? (1.f - momentum) * m + momentum * sr : sr;
+            centre[(size_t)c * F + j] = m;
+        }
+        if (nf > 0 && (was_seen || nr > 0)) {
+            float sf = 0.f;
+            for (int r = f0; r < f1; ++r)
+                if (labels_f[r - f0] == c) sf += to_f32(h[(size_t)r * ld + j]);
+            const float d = sf / (float)nf - m;
+            part += 0.5f * d * d;
+            const float g = d * gscale / (float)nf;
+            for (int r = f0; r < f1; ++r)
+                if (labels_f[r - f0] == c) dh[(size_t)r * ld + j] = from_f32<T>(to_f32(dh[(size_t)r * ld + j]) + g);
+        }
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) {
+        loss_c[c] = red[0];
+        if (nr > 0) seen[c] = 1;
+    }
+}
+
+// Pairwise feature reconstruction (the paper's L_G feature terms): row f0 + i (the reconstruction of image
+// i) is pulled towards row r0 + i (the real image, a constant target): loss = mean_i 1/2 |h_f - h_r|^2,
+// gradient (h_f - h_r) * gscale / n ADDED to row f0 + i of dh.  One block per pair.
+template <typename T>
+__global__ void __launch_bounds__(256) pair_feature_match(const T* __restrict__ h, int ld, int F, int r0, int f0, int n,
+                                                          float gscale, float* __restrict__ loss_row, T* __restrict__ dh) {
+    __shared__ float red[256];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float part = 0.f;
+    for (int j = tid; j < F; j += 256) {
+        const float d = to_f32(h[(size_t)(f0 + i) * ld + j]) - to_f32(h[(size_t)(r0 + i) * ld + j]);
+        part += 0.5f * d * d;
+        T* p = dh + (size_t)(f0 + i) * ld + j;
+        *p = from_f32<T>(to_f32(*p) + d * gscale / (float)n);
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) loss_row[i] = red[0];
+}
+
 __global__ void axpy_f32(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += alpha * x[i];
@@ -1407,6 +1475,31 @@ int cvg_gan_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t M, i
               f0 < f1 && f1 <= M, "gan_feature_match: bad args");
     DISPATCH(dtype, feature_match<T><<<1, 1024, 0, (hipStream_t)stream>>>((const T*)h, ld, M, F, r0, r1, f0, f1,
                                                                           grad_scale, loss, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_gan_class_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t F, const int32_t* labels_real,
+                                const int32_t* labels_fake, int32_t r0, int32_t r1, int32_t f0, int32_t f1, int32_t n_class,
+                                float* centres, int32_t* seen, float momentum, float grad_scale, float* loss, void* dh,
+                                float* ws, cvg_stream stream) {
+    CVG_CHECK(h && labels_real && labels_fake && centres && seen && loss && dh && ws && F > 0 && ld >= F && n_class > 0 &&
+              0 <= r0 && r0 < r1 && 0 <= f0 && f0 < f1, "gan_class_feature_match: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype, class_feature_match<T><<<n_class, 256, 0, s>>>((const T*)h, ld, F, labels_real, labels_fake, r0, r1, f0, f1,
+                                                                   centres, seen, momentum, grad_scale, ws, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    mse_finalize<<<1, 256, 0, s>>>(ws, n_class, loss, 1.f);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_gan_pair_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t F, int32_t r0, int32_t f0, int32_t n,
+                               float grad_scale, float* loss, void* dh, float* ws, cvg_stream stream) {
+    CVG_CHECK(h && loss && dh && ws && F > 0 && ld >= F && n > 0 && r0 >= 0 && f0 >= 0 && (r0 + n <= f0 || f0 + n <= r0),
+              "gan_pair_feature_match: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype, pair_feature_match<T><<<n, 256, 0, s>>>((const T*)h, ld, F, r0, f0, n, grad_scale, ws, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    mse_finalize<<<1, 256, 0, s>>>(ws, n, loss, 1.f / (float)n);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -99,19 +99,20 @@ class CVAE(object):
         # CVAE; no counterpart in the reference's trainer); self.engine stays the CVAE either way
         self.gan = None
         if getattr(args, "gan", False) or getattr(args, "gan_type", "VAE").upper() in ("CVAEGAN", "CVAE-GAN", "GAN"):
-            if self.world > 1:
-                raise NotImplementedError("--gan_type CVAEGAN trains on one GPU: the critics' gradients have no exchange yet")
             from .gan import CVAEGAN
-            self.gan = CVAEGAN(self.pix_dim, self.y_dim, self.z_dim, self.batch_size, dtype=self.dtype,
+            self.gan = CVAEGAN(self.pix_dim, self.y_dim, self.z_dim, self.local_batch, dtype=self.dtype,
                                device=self.device, seed=seed,
-                               lam_gd=getattr(args, "lam_gd", 1e-3), lam_gc=getattr(args, "lam_gc", 1e-3))
+                               lam_gd=getattr(args, "lam_gd", 1e-3), lam_gc=getattr(args, "lam_gc", 1e-3),
+                               lam_pd=getattr(args, "lam_pd", 1e-3), lam_pc=getattr(args, "lam_pc", 1e-3))
             self.engine = self.gan.vae
         else:
             self.engine = Engine(self.pix_dim, self.y_dim, self.z_dim, self.local_batch, dtype=self.dtype,
                                  device=self.device, seed=seed)
         self._sample_engine = None
         self.sync = None
-        if self.world > 1:
+        if self.world > 1 and self.gan is not None:
+            self.gan.broadcast_state()                            # the three arenas are summed after backward
+        elif self.world > 1:
             ddp.broadcast_state(self.engine)                      # every replica starts from rank 0's state
             self.sync = ddp.GradSync.for_engine(self.engine)
             self.engine.grad_ready = self.sync.on_ready
@@ -203,9 +204,9 @@ class CVAE(object):
         eps = torch.empty(self.local_batch, self.z_dim, device=self.device)
         if self.gan is not None:
             hist.update(D_loss=[], C_loss=[])
-            z_p = torch.empty(self.batch_size, self.z_dim, device=self.device)
-            y_p = torch.zeros(self.batch_size, self.y_dim, device=self.device)
-            rows = torch.arange(self.batch_size, device=self.device)
+            z_p = torch.empty(self.local_batch, self.z_dim, device=self.device)
+            y_p = torch.zeros(self.local_batch, self.y_dim, device=self.device)
+            rows = torch.arange(self.local_batch, device=self.device)
         start_time = time.time()
         iters = 0
         for epoch in range(self.epoch):
@@ -215,11 +216,11 @@ class CVAE(object):
                 eps.normal_(generator=self._eps_gen)
                 eng.random_mask()
                 if self.gan is not None:
-                    z_p.normal_()
+                    z_p.normal_(generator=self._eps_gen)
                     y_p.zero_()
-                    y_p[rows, torch.randint(0, self.y_dim, (self.batch_size,), device=self.device)] = 1
+                    y_p[rows, torch.randint(0, self.y_dim, (self.local_batch,), device=self.device, generator=self._eps_gen)] = 1
                     self.gan.gen2.random_mask()
-                    self.gan.train_step(x, cls, eps, z_p, y_p, float(self.batch_size), self.lr)
+                    self.gan.train_step(x, cls, eps, z_p, y_p, float(self.batch_size), self.lr, world=self.world)
                 else:
                     self.train_step(x, cls, eps)
                 iters += 1
@@ -229,7 +230,8 @@ class CVAE(object):
                         gl = self.gan.read_losses()
                         hist["D_loss"].append(gl["D"])
                         hist["C_loss"].append(gl["C"])
-                        print("            D_loss: %.6f C_loss: %.6f GD: %.6f GC: %.6f" % (gl["D"], gl["C"], gl["GD"], gl["GC"]))
+                        self._print("            D_loss: %.6f C_loss: %.6f GD: %.6f GC: %.6f PD: %.6f PC: %.6f" %
+                                    (gl["D"], gl["C"], gl["GD"], gl["GC"], gl["PD"], gl["PC"]))
                     hist["VAE_loss"].append(l["VAE"])
                     hist["KL_loss"].append(l["KL"])
                     hist["LL_loss"].append(l["LL"])

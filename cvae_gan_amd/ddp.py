@@ -193,6 +193,19 @@ def allreduce_mean(t, group=None):
     return out / dist.get_world_size(group)
 
 
+def allreduce_sum_(t, group=None):
+    """In-place SUM over the ranks of a device tensor on the current stream (a critic's gradient arena)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    return t
+
+
 def env_world():
     """(rank, local_rank, world_size) from the launcher's environment (torchrun); (0, 0, 1) without one."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),

@@ -12,12 +12,18 @@ One step, for real images x with labels c, eps for the sampler and prior draws (
     D and C each see ONE joint batch [x | x_f | x_p] (BatchNorm statistics over all 3B rows)
     L_D  = BCE(D(x), 1) + BCE(D(x_f), 0) + BCE(D(x_p), 0)      (mean over the 3B rows)  -> D
     L_C  = CE(C(x), c)                                                                 -> C
-    L_GD = 1/2 |mean f_D(x) - mean f_D(x_p)|^2,  L_GC likewise with f_C   (mean feature matching;
-           f = the trunk output; the real-image mean is a constant target)             -> G (and E)
-    L_VAE = KL + LL as in models/cvae.py:137-140                                        -> E, G
-E and G minimise L_VAE + lam_gd * L_GD + lam_gc * L_GC with D and C held constant; the image gradients
-of the matching losses reach x_p and, through the joint BatchNorm statistics, x_f.  The paper's
-per-class feature centres and pairwise feature reconstruction terms are not included.
+    L_GD = 1/2 |mean f_D(x) - mean f_D(x_p)|^2          (mean feature matching; f = the trunk output; the
+           real-image mean is a constant target)                                        -> G (and E)
+    L_GC = sum_c 1/2 |centre_c - mean_{x_p of class c} f_C|^2   (per-class feature centres: centre_c is the
+           moving average, momentum 0.1, of the mean f_C over the real images of class c; a constant
+           target.  per_class=False: the class-blind form of L_GD instead)              -> G (and E)
+    L_PD = mean_i 1/2 |f_D(x_i) - f_D(x_f,i)|^2,  L_PC likewise with f_C   (pairwise feature reconstruction,
+           the feature terms of the paper's L_G; the real features are constant targets) -> G, E
+    L_VAE = KL + LL as in models/cvae.py:137-140 (LL is the pixel term of the paper's L_G) -> E, G
+E and G minimise L_VAE + lam_gd L_GD + lam_gc L_GC + lam_pd L_PD + lam_pc L_PC with D and C held constant;
+the image gradients of the matching losses reach x_p and x_f (and, through the joint BatchNorm statistics,
+each other).  Data parallel: every loss gradient takes loss_scale = 1 / world and the three gradient
+arenas are summed over the ranks (all_reduce_grads); BatchNorm statistics and class centres stay per replica.
 """
 from collections import OrderedDict
 
@@ -44,7 +50,7 @@ class Critic:
         self.dh_own = torch.zeros(rows, features, dtype=dtype, device=t.device)     # from the critic's own loss
         self.dh_gen = torch.zeros(rows, features, dtype=dtype, device=t.device)     # from the matching loss
         self.ws = torch.zeros(rows * max(n_out, 1) + 2 * rows + 16, dtype=torch.float32, device=t.device)
-        self.losses = torch.zeros(2, dtype=torch.float32, device=t.device)          # [own, matching]
+        self.losses = torch.zeros(3, dtype=torch.float32, device=t.device)          # [own, matching, pairwise]
 
     @property
     def params(self):
@@ -70,9 +76,11 @@ class Critic:
 
 class CVAEGAN:
     def __init__(self, pix_dim, y_dim, z_dim, batch, dtype=torch.bfloat16, ngf=64, n_stage=4, features=64,
-                 lam_gd=1e-3, lam_gc=1e-3, device="cuda", seed=0, state=None):
+                 lam_gd=1e-3, lam_gc=1e-3, lam_pd=1e-3, lam_pc=1e-3, per_class=True, centre_momentum=0.1,
+                 device="cuda", seed=0, state=None):
         self.B, self.P, self.y, self.z = batch, pix_dim, y_dim, z_dim
-        self.lam_gd, self.lam_gc = lam_gd, lam_gc
+        self.lam_gd, self.lam_gc, self.lam_pd, self.lam_pc = lam_gd, lam_gc, lam_pd, lam_pc
+        self.per_class, self.centre_momentum = per_class, centre_momentum
         kw = dict(dtype=dtype, ngf=ngf, n_stage=n_stage, device=device)
         self.vae = Engine(pix_dim, y_dim, z_dim, batch, seed=seed, state=state, **kw)
         # second pass through the generator (the prior samples): same weights, gradients of its own
@@ -82,13 +90,17 @@ class CVAEGAN:
         dev = self.vae.device
         self.x3 = torch.zeros(3 * batch, 3, pix_dim, pix_dim, dtype=torch.float32, device=dev)
         self.labels_dev = torch.zeros(3 * batch, dtype=torch.int32, device=dev)
+        self.labels_p = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.centres = torch.zeros(y_dim, features, dtype=torch.float32, device=dev)      # class centres of f_C over real images
+        self.centres_seen = torch.zeros(y_dim, dtype=torch.int32, device=dev)
 
-    def forward_backward(self, x, labels, eps, z_p, y_p, batch_size):
+    def forward_backward(self, x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0):
         """x f32 NCHW [B,3,P,P]; labels int32 [B]; eps, z_p f32 [B,z]; y_p one-hot f32 [B,y].  The two
-        dropout masks are the ones last set on self.vae / self.gen2.  Gradients land in the four
-        networks' arenas; losses: self.vae.losses[0:2] = KL, LL; self.D.losses / self.C.losses =
-        [own loss, matching loss]."""
+        dropout masks are the ones last set on self.vae / self.gen2.  Gradients (times loss_scale) land in
+        the four networks' arenas; losses: self.vae.losses[0:2] = KL, LL; self.D.losses / self.C.losses =
+        [own loss, matching loss, pairwise loss]."""
         A, G2, D, C, B = self.vae, self.gen2, self.D, self.C, self.B
+        ls = float(loss_scale)
         # ---- E, G forward
         h = A.enc_forward(x, labels)
         zin = A.sample(h, eps, batch_size)
@@ -98,46 +110,69 @@ class CVAEGAN:
         self.x3[B:2 * B].copy_(dec_f)
         self.x3[2 * B:].copy_(dec_p)
         self.labels_dev[:B].copy_(A.enc["labels"])        # the copy enc_forward made: inside [0, y)
+        self.labels_p.copy_(y_p.argmax(dim=1))
         # ---- critics: own losses (parameter gradients), then the matching losses (image gradients)
         M, F = 3 * B, D.F
         hD = D.forward(self.x3)
-        ops.gan_d_head(hD, F, D.params["head.weight"], D.params["head.bias"], M, F, B, 1.0, D.grads["head.weight"],
+        ops.gan_d_head(hD, F, D.params["head.weight"], D.params["head.bias"], M, F, B, ls, D.grads["head.weight"],
                        D.grads["head.bias"], D.losses[0:1], D.dh_own, D.ws)
-        ops.gan_feature_match(hD, F, M, F, 0, B, 2 * B, M, self.lam_gd, D.losses[1:2], D.dh_gen)
+        ops.gan_feature_match(hD, F, M, F, 0, B, 2 * B, M, self.lam_gd * ls, D.losses[1:2], D.dh_gen)
+        ops.gan_pair_feature_match(hD, F, F, 0, B, B, self.lam_pd * ls, D.losses[2:3], D.dh_gen, D.ws)
         D.backward_own()
         dimg_d = D.backward_generator()
         hC = C.forward(self.x3)
-        ops.gan_c_head(hC, F, C.params["head.weight"], C.params["head.bias"], self.labels_dev, M, F, self.y, B, 1.0,
+        ops.gan_c_head(hC, F, C.params["head.weight"], C.params["head.bias"], self.labels_dev, M, F, self.y, B, ls,
                        C.grads["head.weight"], C.grads["head.bias"], C.losses[0:1], C.dh_own, C.ws)
-        ops.gan_feature_match(hC, F, M, F, 0, B, 2 * B, M, self.lam_gc, C.losses[1:2], C.dh_gen)
+        if self.per_class:
+            C.dh_gen.zero_()
+            ops.gan_class_feature_match(hC, F, F, self.labels_dev, self.labels_p, 0, B, 2 * B, M, self.y, self.centres,
+                                        self.centres_seen, self.centre_momentum, self.lam_gc * ls, C.losses[1:2],
+                                        C.dh_gen, C.ws)
+        else:
+            ops.gan_feature_match(hC, F, M, F, 0, B, 2 * B, M, self.lam_gc * ls, C.losses[1:2], C.dh_gen)
+        ops.gan_pair_feature_match(hC, F, F, 0, B, B, self.lam_pc * ls, C.losses[2:3], C.dh_gen, C.ws)
         C.backward_own()
         dimg_c = C.backward_generator()
         # ---- generator / encoder backward
         d = A.dec
-        ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, 1.0, A.red_ws)
+        ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, ls, A.red_ws)
         ops.axpy(d["d_dec"], dimg_d[B:2 * B], 1.0)
         ops.axpy(d["d_dec"], dimg_c[B:2 * B], 1.0)
         G2.dec["d_dec"].copy_(dimg_d[2 * B:])
         ops.axpy(G2.dec["d_dec"], dimg_c[2 * B:], 1.0)
         dzin = A.dec_backward(d["d_dec"], d["mask"])
-        A.sample_backward(dzin, eps, None, None, 1.0, batch_size)
+        A.sample_backward(dzin, eps, None, None, ls, batch_size)
         A.enc_backward(A.enc["dh"])
         G2.dec_backward(G2.dec["d_dec"], G2.dec["mask"])
         ops.axpy(A.g_arena, G2.g_arena, 1.0)
         return dec_f, dec_p
+
+    def all_reduce_grads(self):
+        """Data parallel: sum the gradient arenas of the CVAE, the discriminator and the classifier over
+        the ranks (each rank ran forward_backward with loss_scale = 1 / world)."""
+        from . import ddp
+        for arena in (self.vae.g_arena, self.D.trunk.g_arena, self.C.trunk.g_arena):
+            ddp.allreduce_sum_(arena)
+
+    def broadcast_state(self, src=0):
+        from . import ddp
+        for eng in (self.vae, self.D.trunk, self.C.trunk):
+            ddp.broadcast_state(eng, src=src)
 
     def adamw_step(self, lr):
         self.vae.adamw_step(lr)
         self.D.adamw_step(lr)
         self.C.adamw_step(lr)
 
-    def train_step(self, x, labels, eps, z_p, y_p, batch_size, lr):
-        out = self.forward_backward(x, labels, eps, z_p, y_p, batch_size)
+    def train_step(self, x, labels, eps, z_p, y_p, batch_size, lr, world=1):
+        out = self.forward_backward(x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0 / world)
+        if world > 1:
+            self.all_reduce_grads()
         self.adamw_step(lr)
         return out
 
     def read_losses(self):
         kl, ll = self.vae.losses[:2].tolist()
-        ld, lgd = self.D.losses.tolist()
-        lc, lgc = self.C.losses.tolist()
-        return dict(KL=kl, LL=ll, D=ld, C=lc, GD=lgd, GC=lgc)
+        ld, lgd, lpd = self.D.losses.tolist()
+        lc, lgc, lpc = self.C.losses.tolist()
+        return dict(KL=kl, LL=ll, D=ld, C=lc, GD=lgd, GC=lgc, PD=lpd, PC=lpc)

@@ -270,6 +270,17 @@ def gan_feature_match(h, ld, M, F, r0, r1, f0, f1, grad_scale, loss, dh):
     check(lib.cvg_gan_feature_match(ptr(h), dt(h), ld, M, F, r0, r1, f0, f1, grad_scale, ptr(loss), ptr(dh), stream()))
 
 
+def gan_class_feature_match(h, ld, F, labels_real, labels_fake, r0, r1, f0, f1, n_class, centres, seen, momentum,
+                            grad_scale, loss, dh, ws):
+    check(lib.cvg_gan_class_feature_match(ptr(h), dt(h), ld, F, ptr(labels_real), ptr(labels_fake), r0, r1, f0, f1, n_class,
+                                          ptr(centres), ptr(seen), momentum, grad_scale, ptr(loss), ptr(dh), ptr(ws),
+                                          stream()))
+
+
+def gan_pair_feature_match(h, ld, F, r0, f0, n, grad_scale, loss, dh, ws):
+    check(lib.cvg_gan_pair_feature_match(ptr(h), dt(h), ld, F, r0, f0, n, grad_scale, ptr(loss), ptr(dh), ptr(ws), stream()))
+
+
 def axpy(y, x, alpha, n=None):
     """y += alpha * x (f32)."""
     assert y.dtype == torch.float32 and x.dtype == torch.float32

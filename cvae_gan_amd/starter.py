@@ -38,6 +38,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--lam_gd", type=float, default=1e-3, help="weight of the discriminator feature-matching loss")
     p.add_argument("--lam_gc", type=float, default=1e-3, help="weight of the classifier feature-matching loss")
+    p.add_argument("--lam_pd", type=float, default=1e-3, help="weight of the pairwise discriminator-feature loss")
+    p.add_argument("--lam_pc", type=float, default=1e-3, help="weight of the pairwise classifier-feature loss")
     return p
 
 

@@ -358,6 +358,22 @@ int cvg_gan_c_head(const void* h, int32_t dtype, int32_t ld, const float* W, con
 int cvg_gan_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t M, int32_t F,
                           int32_t r0, int32_t r1, int32_t f0, int32_t f1, float grad_scale,
                           float* loss, void* dh, cvg_stream s);
+/* Per-class feature centres (the paper's L_GC).  labels_real int32 [r1 - r0] and labels_fake int32 [f1 - f0]
+ * are the classes of the rows [r0, r1) (real images) and [f0, f1) (generated images) of h.  centres f32
+ * [n_class][F] and seen int32 [n_class] are state kept by the caller across steps (start at zero): the centre
+ * of a class is the moving average (momentum) of the mean feature of its real rows, taken over as is the first
+ * time the class appears.  loss = sum over classes with generated rows of 1/2 |mean_fake_c - centre_c|^2; the
+ * gradient grad_scale * (mean_fake_c - centre_c) / n_fake_c is ADDED to the generated rows of dh (other rows
+ * untouched, so it composes with cvg_gan_feature_match, which writes every row).  ws >= n_class floats.     */
+int cvg_gan_class_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t F, const int32_t* labels_real,
+                                const int32_t* labels_fake, int32_t r0, int32_t r1, int32_t f0, int32_t f1,
+                                int32_t n_class, float* centres, int32_t* seen, float momentum, float grad_scale,
+                                float* loss, void* dh, float* ws, cvg_stream s);
+/* Pairwise feature reconstruction (the feature terms of the paper's L_G): loss = mean over i < n of
+ * 1/2 |h[f0 + i] - h[r0 + i]|^2 with row r0 + i (the real image) a constant target; the gradient
+ * grad_scale * (h[f0 + i] - h[r0 + i]) / n is ADDED to row f0 + i of dh.  ws >= n floats.                   */
+int cvg_gan_pair_feature_match(const void* h, int32_t dtype, int32_t ld, int32_t F, int32_t r0, int32_t f0,
+                               int32_t n, float grad_scale, float* loss, void* dh, float* ws, cvg_stream s);
 /* y += alpha * x over n floats (gradient arenas of two passes over shared weights, image
  * gradients arriving from several critics).                                                     */
 int cvg_axpy_f32(float* y, const float* x, float alpha, int64_t n, cvg_stream s);

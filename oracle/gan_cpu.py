@@ -39,10 +39,23 @@ def _const(sd):
     return OrderedDict((k, v.detach()) for k, v in sd.items())
 
 
+def class_centres(fC_real, labels, centres, seen, momentum):
+    """Moving-average centres of the real images' classifier features per class (a constant target):
+    a class seen for the first time takes its batch mean as is.  Returns new (centres, seen)."""
+    centres, seen = centres.clone(), seen.clone()
+    for c in labels.unique().tolist():
+        m = fC_real[labels == c].mean(0).detach()
+        centres[c] = (1 - momentum) * centres[c] + momentum * m if bool(seen[c]) else m
+        seen[c] = 1
+    return centres, seen
+
+
 def step_gradients(enc_sd, dec_sd, d_sd, c_sd, x, labels, eps, mask_f, z_p, labels_p, mask_p, y_dim, batch_size,
-                   lam_gd, lam_gc, n_stage=R.N_STAGE):
+                   lam_gd, lam_gc, n_stage=R.N_STAGE, lam_pd=0.0, lam_pc=0.0, per_class=False, centres=None, seen=None,
+                   momentum=0.1):
     """Losses and gradients of one CVAE-GAN step as cvae_gan_amd/gan.py defines it.
-    Returns (losses dict, grads dict per network, images dict)."""
+    Returns (losses dict, grads dict per network, images dict); with per_class the images dict also
+    holds the updated class centres."""
     enc, dec, dd, cc = _leaf(enc_sd), _leaf(dec_sd), _leaf(d_sd), _leaf(c_sd)
     B = x.shape[0]
     planes = R.label_planes(labels, y_dim, x.shape[-1], x.dtype)
@@ -65,9 +78,21 @@ def step_gradients(enc_sd, dec_sd, d_sd, c_sd, x, labels, eps, mask_f, z_p, labe
     fD = trunk(_const(dd), x3, n_stage)
     fC = trunk(_const(cc), x3, n_stage)
     L_GD = 0.5 * ((fD[2 * B:].mean(0) - fD[:B].mean(0).detach()) ** 2).sum()
-    L_GC = 0.5 * ((fC[2 * B:].mean(0) - fC[:B].mean(0).detach()) ** 2).sum()
+    extra = {}
+    if per_class:
+        centres, seen = class_centres(fC[:B], labels, centres, seen, momentum)
+        L_GC = fC.new_zeros(())
+        for c in labels_p.unique().tolist():
+            if bool(seen[c]):
+                L_GC = L_GC + 0.5 * ((fC[2 * B:][labels_p == c].mean(0) - centres[c]) ** 2).sum()
+        extra.update(centres=centres, seen=seen)
+    else:
+        L_GC = 0.5 * ((fC[2 * B:].mean(0) - fC[:B].mean(0).detach()) ** 2).sum()
+    # pairwise feature reconstruction: the reconstruction's features against the real image's (constants)
+    L_PD = 0.5 * ((fD[B:2 * B] - fD[:B].detach()) ** 2).sum(1).mean()
+    L_PC = 0.5 * ((fC[B:2 * B] - fC[:B].detach()) ** 2).sum(1).mean()
     vae, kl, ll = R.losses(dec_f, x, mu, sigma, batch_size)
-    L_EG = vae + lam_gd * L_GD + lam_gc * L_GC
+    L_EG = vae + lam_gd * L_GD + lam_gc * L_GC + lam_pd * L_PD + lam_pc * L_PC
 
     def grads(loss, sd):
         keys = [k for k, v in sd.items() if v.requires_grad]
@@ -75,5 +100,6 @@ def step_gradients(enc_sd, dec_sd, d_sd, c_sd, x, labels, eps, mask_f, z_p, labe
         return OrderedDict((k, g if g is not None else torch.zeros_like(sd[k])) for k, g in zip(keys, gs))
 
     out_g = dict(D=grads(L_D, dd), C=grads(L_C, cc), E=grads(L_EG, enc), G=grads(L_EG, dec))
-    losses = {k: float(v.detach()) for k, v in dict(KL=kl, LL=ll, D=L_D, C=L_C, GD=L_GD, GC=L_GC).items()}
-    return losses, out_g, dict(dec_f=dec_f.detach(), dec_p=dec_p.detach(), hD=hD.detach(), hC=hC.detach())
+    losses = {k: float(v.detach()) for k, v in dict(KL=kl, LL=ll, D=L_D, C=L_C, GD=L_GD, GC=L_GC, PD=L_PD, PC=L_PC).items()}
+    extra.update(dec_f=dec_f.detach(), dec_p=dec_p.detach(), hD=hD.detach(), hC=hC.detach())
+    return losses, out_g, extra

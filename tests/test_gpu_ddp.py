@@ -91,3 +91,18 @@ def test_trainer_two_ranks_share_one_gpu(tmp_path):
     d = os.path.join(str(tmp_path / "ck"), "VAE_data_Synth_pix_32_batch_16_embed_8")
     enc = torch.load(os.path.join(d, "Synth_encoder.pkl"), weights_only=True)
     assert len(enc) == 68 and all(torch.isfinite(v.float()).all() for v in enc.values())
+
+
+def test_gan_trainer_two_ranks(tmp_path):
+    """--gan_type CVAEGAN under two ranks: the CVAE's, the discriminator's and the classifier's gradient
+    arenas are summed over the ranks after backward; rank 0 writes all four checkpoints."""
+    out = _run_ranks(["-m", "cvae_gan_amd.starter", "--dataset", "Synth", "--data_dir", str(tmp_path / "none"),
+                      "--data_size", "64", "--pix_dim", "32", "--y_dim", "4", "--z_dim", "8", "--batch_size", "16",
+                      "--epoch", "1", "--max_iters", "2", "--lrG", "1e-3", "--worker", "0", "--gpus", "0",
+                      "--gan_type", "CVAEGAN", "--save_dir", str(tmp_path / "ck"), "--result_dir", str(tmp_path / "res")], 2,
+                     extra_env={"CVG_DDP_BACKEND": "gloo", "CVG_DDP_SHARE_GPU": "1"})
+    assert "Training finish" in out[0]
+    d = os.path.join(str(tmp_path / "ck"), "VAE_data_Synth_pix_32_batch_16_embed_8")
+    for name in ("encoder", "decoder", "discriminator", "classifier"):
+        sd = torch.load(os.path.join(d, "Synth_%s.pkl" % name), weights_only=True)
+        assert all(torch.isfinite(v.float()).all() for v in sd.values()), name

@@ -15,7 +15,7 @@ def relmax(a, b):
     return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
 
 
-def _setup(seed=0):
+def _setup(seed=0, **gan_kw):
     from cvae_gan_amd.gan import CVAEGAN
     from oracle import gan_cpu, ref_cpu
     P, y, z, B, ngf, F = 16, 4, 8, 4, 8, 16
@@ -33,7 +33,9 @@ def _setup(seed=0):
     c_sd = gan_cpu.critic_params(P, y, F, seed=12, ngf=ngf)
     state = dict(enc_sd)
     state.update(dec_sd)
-    net = CVAEGAN(P, y, z, B, dtype=torch.float32, ngf=ngf, features=F, lam_gd=0.5, lam_gc=0.25, state=state)
+    kw = dict(lam_gd=0.5, lam_gc=0.25, lam_pd=0.0, lam_pc=0.0, per_class=False)
+    kw.update(gan_kw)
+    net = CVAEGAN(P, y, z, B, dtype=torch.float32, ngf=ngf, features=F, state=state, **kw)
     net.D.trunk.load_state(d_sd)
     net.C.trunk.load_state(c_sd)
     net.vae.set_mask(mask_f)
@@ -43,23 +45,36 @@ def _setup(seed=0):
     return net, cpu
 
 
-def test_gan_step_losses_and_gradients():
+@pytest.mark.parametrize("full", [False, True])
+def test_gan_step_losses_and_gradients(full):
+    """full: per-class feature centres (two steps, so that the second one meets centres that the first
+    one left behind and moves them by the momentum rule) and the pairwise feature terms."""
     from oracle import gan_cpu, ref_cpu
-    net, c = _setup()
+    kw = dict(lam_pd=0.3, lam_pc=0.2, per_class=True) if full else {}
+    net, c = _setup(**kw)
     P, y, z, B, ngf, F = c["dims"]
-    losses, grads, imgs = gan_cpu.step_gradients(c["enc"], c["dec"], c["d"], c["c"], c["x"], c["labels"], c["eps"],
-                                                 c["mask_f"], c["z_p"], c["labels_p"], c["mask_p"], y, float(B),
-                                                 0.5, 0.25)
     dev = "cuda"
-    y_p = ref_cpu.one_hot(c["labels_p"], y).to(dev)
-    dec_f, dec_p = net.forward_backward(c["x"].to(dev), c["labels"].to(dev).int(), c["eps"].to(dev), c["z_p"].to(dev),
-                                        y_p, float(B))
-    torch.cuda.synchronize()
+    centres, seen = torch.zeros(y, F), torch.zeros(y, dtype=torch.int32)
+    for step in range(2 if full else 1):
+        # the second step swaps the roles of the two label vectors: other classes among the real rows
+        lab, lab_p = (c["labels"], c["labels_p"]) if step == 0 else (c["labels_p"], c["labels"])
+        losses, grads, imgs = gan_cpu.step_gradients(c["enc"], c["dec"], c["d"], c["c"], c["x"], lab, c["eps"],
+                                                     c["mask_f"], c["z_p"], lab_p, c["mask_p"], y, float(B),
+                                                     0.5, 0.25, per_class=full, centres=centres, seen=seen, **
+                                                     ({"lam_pd": 0.3, "lam_pc": 0.2} if full else {}))
+        if full:
+            centres, seen = imgs["centres"], imgs["seen"]
+        dec_f, dec_p = net.forward_backward(c["x"].to(dev), lab.to(dev).int(), c["eps"].to(dev), c["z_p"].to(dev),
+                                            ref_cpu.one_hot(lab_p, y).to(dev), float(B))
+        torch.cuda.synchronize()
     assert relmax(dec_f.cpu(), imgs["dec_f"]) < 1e-4
     assert relmax(dec_p.cpu(), imgs["dec_p"]) < 1e-4
     got = net.read_losses()
-    for k in ("KL", "LL", "D", "C", "GD", "GC"):
+    for k in ("KL", "LL", "D", "C", "GD", "GC") + (("PD", "PC") if full else ()):
         assert abs(got[k] - losses[k]) <= 1e-4 * max(abs(losses[k]), 1e-3), (k, got[k], losses[k])
+    if full:
+        assert net.centres_seen.cpu().tolist() == seen.tolist()
+        assert relmax(net.centres.cpu(), centres) < 1e-4
     checked = 0
     for name, eng in (("D", net.D.trunk), ("C", net.C.trunk), ("E", net.vae), ("G", net.vae)):
         for k, ref in grads[name].items():
