@@ -83,6 +83,7 @@ def _load():
         "cvg_permute_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
         "cvg_reparam_kl_fwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
         "cvg_reparam_kl_bwd": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
+        "cvg_labels_prepare": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "cvg_lrelu_dropout_fwd": (C.c_int, [vp, vp, vp, i32, i64, vp]),
         "cvg_lrelu_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i32, i64, vp]),
         "cvg_dropout_mask": (C.c_int, [vp, i64, C.c_uint64, vp]),

@@ -699,6 +699,18 @@ __global__ void reparam_kl_bwd(const T* __restrict__ dzin, int zin_ld, const flo
     dh[(size_t)b * 2 * z + z + j] = from_f32<T>(dls);
 }
 
+// ---- class indices: copy, keep inside [0, n_class), flag the ones that were not --------------------
+__global__ void labels_prepare(const int* __restrict__ in, int* __restrict__ out, int n, int n_class, float* bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int v = in[i];
+    if (v < 0 || v >= n_class) {
+        *bad = 1.f;                     // every offender stores the same value: no ordering needed
+        v = v < 0 ? 0 : n_class - 1;
+    }
+    out[i] = v;
+}
+
 // ---- LeakyReLU + Dropout(0.5) ------------------------------------------------------------------
 template <typename T>
 __global__ void lrelu_dropout_fwd(const T* __restrict__ x, const uint8_t* __restrict__ mask, T* __restrict__ y,
@@ -1283,6 +1295,13 @@ int cvg_reparam_kl_bwd(const void* dzin, int32_t dtype, int32_t zin_ld, const fl
     CVG_CHECK(dzin && eps && z_mean && z_sigma && dh && B > 0 && z > 0, "reparam_kl_bwd: bad args");
     DISPATCH(dtype, reparam_kl_bwd<T><<<grid1((int64_t)B * z), 256, 0, (hipStream_t)stream>>>(
                         (const T*)dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, (T*)dh));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cvg_labels_prepare(const int32_t* labels, int32_t* out, int32_t n, int32_t n_class, float* bad, cvg_stream stream) {
+    CVG_CHECK(labels && out && bad && n > 0 && n_class > 0, "labels_prepare: bad args");
+    labels_prepare<<<grid1(n), 256, 0, (hipStream_t)stream>>>(labels, out, n, n_class, bad);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -193,7 +193,10 @@ class CVAE(object):
 
     def read_losses(self):
         """The losses of the whole (global) batch: the mean of the ranks' values."""
-        kl, ll = ddp.allreduce_mean(self.engine.losses[:2]).tolist()
+        kl, ll, bad = ddp.allreduce_mean(self.engine.losses[:3]).tolist()
+        if bad != 0.0:          # some rank's encoder met a class index outside [0, y_dim): every rank raises
+            self.engine.losses[2:3].zero_()
+            raise ValueError("a class label outside [0, %d) reached the encoder" % self.y_dim)
         return {"VAE": kl + ll, "KL": kl, "LL": ll}
 
     def train(self):

@@ -558,7 +558,7 @@ class Engine:
         d["bgradF8"] = self._f(F8)
         self.eps = self._f(B, self.z)
         self.z_mean, self.z_sigma = self._f(B, self.z), self._f(B, self.z)
-        self.losses = self._f(4)          # [kl, ll, -, -]
+        self.losses = self._f(4)          # [kl, ll, bad-label flag, -]
         self.step_dev = torch.zeros(1, dtype=torch.long, device=self.device)     # AdamW step count
         self.seed_dev = torch.full((1,), self._dropout_start, dtype=torch.long, device=self.device)   # dropout stream position
         self.bc_dev = self._f(2)
@@ -707,9 +707,11 @@ class Engine:
         if self.y > 0:
             # class indices address the per-class bias table, its gradient rows and the one-hot
             # columns of the decoder input: kept inside [0, y) so that a bad index cannot leave
-            # those buffers (validation with an error is the data path's job, it sees host labels)
-            e["labels"].copy_(labels)
-            e["labels"].clamp_(0, self.y - 1)
+            # those buffers; losses[2] records that one was outside and read_losses() raises
+            assert labels.numel() == B
+            if labels.dtype != torch.int32 or not labels.is_contiguous():
+                labels = labels.to(torch.int32).contiguous()
+            ops.labels_prepare(labels, e["labels"], B, self.y, self.losses[2:3])
         ops.pack_image(x, e["xpad"], B, P)
         self._conv_bn(e["stem"], e["xpad"], e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2",
                       bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],
@@ -973,5 +975,8 @@ class Engine:
         return dec
 
     def read_losses(self):
-        kl, ll = self.losses[:2].tolist()
+        kl, ll, bad = self.losses[:3].tolist()
+        if bad != 0.0:
+            self.losses[2:3].zero_()
+            raise ValueError("a class label outside [0, %d) reached the encoder since the last read_losses()" % self.y)
         return {"VAE": kl + ll, "KL": kl, "LL": ll}

@@ -183,6 +183,10 @@ def reparam_kl_bwd(dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale
                                  ptr(g_sigma), float(kl_scale), float(batch_size), B, z, ptr(dh), stream()))
 
 
+def labels_prepare(labels, out, n, n_class, bad):
+    check(lib.cvg_labels_prepare(ptr(labels), ptr(out), n, n_class, ptr(bad), stream()))
+
+
 def lrelu_dropout_fwd(x, mask, y, n):
     check(lib.cvg_lrelu_dropout_fwd(ptr(x), ptr(mask), ptr(y), dt(x), n, stream()))
 

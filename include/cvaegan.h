@@ -270,6 +270,13 @@ int cvg_reparam_kl_bwd(const void* dzin, int32_t dtype, int32_t zin_ld, const fl
                        const float* g_sigma, float kl_scale, float batch_size, int32_t B,
                        int32_t z, void* dh, cvg_stream s);
 
+/* Class indices as the kernels use them: out[i] = labels[i] kept inside [0, n_class); *bad is set to
+ * 1.0f when any index was outside (it is never cleared here: the caller reads and clears it when it
+ * next synchronises).  The reference indexes a one-hot table with the label on the host
+ * (models/cvae.py:124-130), where a bad index raises at once; on the device the error is deferred. */
+int cvg_labels_prepare(const int32_t* labels, int32_t* out, int32_t n, int32_t n_class,
+                       float* bad, cvg_stream s);
+
 /* LeakyReLU(0.2) followed by Dropout(0.5) with an explicit keep mask (uint8, 1 = keep,
  * kept values x2) -- networks.py:154-155.  mask == NULL: eval mode (identity dropout). */
 int cvg_lrelu_dropout_fwd(const void* x, const uint8_t* mask, void* y, int32_t dtype,

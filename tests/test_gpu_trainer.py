@@ -60,7 +60,8 @@ def test_single_image_batch():
 
 def test_label_out_of_range():
     """The data path rejects a class index the one-hot cannot hold (IndexError, as the reference's
-    table lookup at models/cvae.py:129); the engine itself keeps indices inside its tables."""
+    table lookup at models/cvae.py:129).  The engine, which only sees device labels, keeps indices
+    inside its tables while the step runs and raises at the next read_losses()."""
     from cvae_gan_amd.datasets import DevicePrefetcher
     from cvae_gan_amd.engine import Engine
     imgs = torch.zeros(4, 16, 16, 3, dtype=torch.uint8)
@@ -73,10 +74,13 @@ def test_label_out_of_range():
     eps = torch.randn(4, 8, device="cuda")
     eng.random_mask(seed=1)
     eng.forward_backward(x, torch.tensor([0, 1, 7, -3], dtype=torch.int32, device="cuda"), eps, 4.0)
-    a = eng.read_losses()
+    with pytest.raises(ValueError, match="class label outside"):
+        eng.read_losses()
+    a = eng.losses[:2].tolist()
     eng.random_mask(seed=1)
     eng.forward_backward(x, torch.tensor([0, 1, 3, 0], dtype=torch.int32, device="cuda"), eps, 4.0)
-    assert eng.read_losses() == a                         # 7 -> 3, -3 -> 0
+    b = eng.read_losses()                                 # the flag was cleared by the raise
+    assert [b["KL"], b["LL"]] == a                        # the bad step ran as 7 -> 3, -3 -> 0: nothing left its buffers
 
 
 class Args:
