@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         "dtype", "B", "H", "W", "Cin", "x_img_pitch", "x_row_pitch", "x_pix_pitch",
         "OH", "OW", "N", "KW", "ntaps", "stride", "tstep_y", "tstep_x", "off_y", "off_x",
         "pad_mode", "y_img_pitch", "y_row_pitch", "y_pix_pitch", "oy_mul", "oy_off",
-        "ox_mul", "ox_off", "w_ld", "w_rows")]
+        "ox_mul", "ox_off", "w_ld", "w_rows", "co_launches")]
 
 
 class WMap(C.Structure):

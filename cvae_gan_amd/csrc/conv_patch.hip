@@ -1227,6 +1227,17 @@ int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap
     return 0;
 }
 
+// workgroups one weight-gradient launch aims for (the split count follows from it): every CU, or its share
+// of them when the caller runs co_launches such launches side by side.  Two launches over 128 CUs each
+// write and re-read half the partial slabs of two launches over 256 CUs one after the other.
+// CVG_WGRAD_WGS overrides (benchmarking).
+static int wgrad_target_wgs(const cvg_conv_desc* d) {
+    static const int forced = [] { const char* e = getenv("CVG_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+    if (forced >= 16) return forced;
+    const int share = d->co_launches > 1 ? d->co_launches : 1;
+    return 256 / (share > 8 ? 8 : share);
+}
+
 void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     p.ok = 0;
     p.stride = 1;
@@ -1244,7 +1255,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
         p.nchunks = d->Cin / CK;
         p.n_tiles = ceil_div(d->N, p.BNW);
         const double eff = (double)d->B * d->OH * d->OW / ((double)p.ntiles * 128);
-        int want = ceil_div(256, p.nchunks * p.n_tiles);
+        int want = ceil_div(wgrad_target_wgs(d), p.nchunks * p.n_tiles);
         if (want > p.ntiles) want = p.ntiles;
         if (want < 1) want = 1;
         p.tiles_per_split = ceil_div(p.ntiles, want);
@@ -1275,7 +1286,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
             p.nchunks = d->Cin / (CK * wc);                                   // chunk groups
             p.n_tiles = ceil_div(d->N, p.BNW);
             const double eff9 = (double)d->B * d->OH * d->OW / ((double)p.ntiles * 128);
-            int want9 = ceil_div(256, p.nchunks * p.n_tiles);
+            int want9 = ceil_div(wgrad_target_wgs(d), p.nchunks * p.n_tiles);
             if (want9 > p.ntiles) want9 = p.ntiles;
             if (want9 < 1) want9 = 1;
             p.tiles_per_split = ceil_div(p.ntiles, want9);
@@ -1307,7 +1318,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     if (eff < 0.5) return;
     // one workgroup per CU fits (accumulators take the whole register file): aim for ~256 of them,
     // which also halves the partial-slab traffic of the reduce pass compared with two rounds
-    int want = ceil_div(256, p.nchunks * p.n_tiles);
+    int want = ceil_div(wgrad_target_wgs(d), p.nchunks * p.n_tiles);
     if (want > p.ntiles) want = p.ntiles;
     if (want < 1) want = 1;
     p.tiles_per_split = ceil_div(p.ntiles, want);

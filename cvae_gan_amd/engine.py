@@ -564,6 +564,12 @@ class Engine:
         self.bc_dev = self._f(2)
 
     def _build_workspaces(self):
+        # backward's weight-gradient launches alternate between two side streams (CVG_SIDE_STREAMS): two of
+        # them run side by side, each planned for half of the CUs, which halves their split count and with
+        # it the partial-slab traffic (measured -0.17 ms per c3 step against one side stream)
+        self._n_side = max(1, int(os.environ.get("CVG_SIDE_STREAMS", "2"))) if self.overlap else 1
+        for desc in [g.desc for g in self._gemms] + list(self._wgrad_descs):
+            desc.co_launches = self._n_side
         wg = 0
         for g in self._gemms:
             wg = max(wg, ops.conv_wgrad_workspace(g.desc))
@@ -574,9 +580,11 @@ class Engine:
         if self.dec is not None:
             max_c = max(max_c, self.dec["nout"], self.dec["F8"])
         self.red_ws = torch.zeros(2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
-        # the weight-gradient branch of backward runs on a side stream with workspaces of its own
-        self.ws_side = torch.zeros(max(wg, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
-        self.red_ws_side = torch.zeros_like(self.red_ws)
+        # the weight-gradient branches of backward run on side streams with workspaces of their own
+        self._ws_sides = [torch.zeros(max(wg, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
+                          for _ in range(self._n_side)]
+        self._red_ws_sides = [torch.zeros_like(self.red_ws) for _ in range(self._n_side)]
+        self._side_i = 0
         self._bn_scratch = (self._f(max_c), self._f(max_c))
 
     # ------------------------------------------------------------------ helpers
@@ -680,19 +688,30 @@ class Engine:
             yield
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self._n_side)]
+        self._side_i = (self._side_i + 1) % self._n_side
+        side = self._side[self._side_i]
         ev = torch.cuda.Event()
         ev.record()
-        self._side.wait_event(ev)
-        with torch.cuda.stream(self._side):
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
             yield
         self._side_dirty = True
 
+    @property
+    def ws_side(self):
+        return self._ws_sides[self._side_i]
+
+    @property
+    def red_ws_side(self):
+        return self._red_ws_sides[self._side_i]
+
     def _join(self):
         if self._side_dirty:
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-            torch.cuda.current_stream().wait_event(ev)
+            for side in self._side:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                torch.cuda.current_stream().wait_event(ev)
             self._side_dirty = False
 
     # ------------------------------------------------------------------ encoder

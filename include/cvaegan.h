@@ -58,6 +58,10 @@ typedef struct cvg_conv_desc {
     int32_t oy_mul, oy_off, ox_mul, ox_off;
     int32_t w_ld;                    /* weight row length = K padded to 64 (bf16) / 32 (f32) */
     int32_t w_rows;                  /* weight rows allocated (N padded to 128)    */
+    int32_t co_launches;             /* weight gradient only: launches of this kind the caller runs side
+                                        by side on different streams (0 or 1: one).  Each then aims for
+                                        1/co_launches of the CUs, i.e. that fraction of the split count
+                                        and of the partial-slab traffic                              */
 } cvg_conv_desc;
 
 /* Conv2d / Linear forward and input-gradient.
