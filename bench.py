@@ -395,6 +395,7 @@ def main():
     # starts and the clocks are those of a busy GPU: the events then measure kernels, not launch
     # gaps or a clock ramp)
     overlap, eng.overlap = eng.overlap, False
+    eng.set_co_launches(1)               # one stream: every weight-gradient launch has the whole chip
     wa = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
     wb = torch.empty_like(wa)
     with KernelTimer(eng) as kt:
@@ -409,6 +410,7 @@ def main():
         if args.per_layer:
             print(kt.per_layer(2), file=sys.stderr)
     eng.overlap = overlap
+    eng.set_co_launches(eng._n_side)
     name, (fl, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     achieved = fl / t / 1e12

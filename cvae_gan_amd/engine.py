@@ -568,13 +568,13 @@ class Engine:
         # them run side by side, each planned for half of the CUs, which halves their split count and with
         # it the partial-slab traffic (measured -0.17 ms per c3 step against one side stream)
         self._n_side = max(1, int(os.environ.get("CVG_SIDE_STREAMS", "2"))) if self.overlap else 1
-        for desc in [g.desc for g in self._gemms] + list(self._wgrad_descs):
-            desc.co_launches = self._n_side
         wg = 0
-        for g in self._gemms:
-            wg = max(wg, ops.conv_wgrad_workspace(g.desc))
-        for desc in self._wgrad_descs:
-            wg = max(wg, ops.conv_wgrad_workspace(desc))
+        for share in sorted({1, self._n_side}):          # workspaces fit either plan (see set_co_launches)
+            self.set_co_launches(share)
+            for g in self._gemms:
+                wg = max(wg, ops.conv_wgrad_workspace(g.desc))
+            for desc in self._wgrad_descs:
+                wg = max(wg, ops.conv_wgrad_workspace(desc))
         self.ws = torch.zeros(max(wg, self._ws_bytes, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
         max_c = max(self.ngf * 8, 4 * self.z)
         if self.dec is not None:
@@ -586,6 +586,12 @@ class Engine:
         self._red_ws_sides = [torch.zeros_like(self.red_ws) for _ in range(self._n_side)]
         self._side_i = 0
         self._bn_scratch = (self._f(max_c), self._f(max_c))
+
+    def set_co_launches(self, n):
+        """Plan every weight-gradient launch for 1/n of the CUs (n = the number of side streams while they
+        overlap; 1 for a driver that runs the step on one stream, e.g. to time kernels one by one)."""
+        for desc in [g.desc for g in self._gemms] + list(self._wgrad_descs):
+            desc.co_launches = n
 
     # ------------------------------------------------------------------ helpers
     def pack_weights(self, force=False):

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Long-run stability check of the bf16 train step: a few thousand AdamW steps at the benchmark shape on
 class-dependent synthetic images held on the device; prints the losses as they go and fails on a
-non-finite value.    python tools/soak_train.py [steps=3000] [lr=3e-5]
+non-finite value.    python tools/soak_train.py [steps=3000] [lr=3e-5] [bf16|f32] [seed=0]
 
 At the reference's learning rate (3e-5, train.sh) the run first settles on the mean image (LL 0.0215 on
-this data) and leaves that plateau after a number of steps that depends on the initial draw: 600 to
-several thousand."""
+this data: the decoder ignores z and the label) and leaves that plateau after a number of steps that depends
+on the initial draw: seed 3 leaves it between steps 1000 and 2000 and reaches LL 0.0016 by step 6000; seeds
+0, 1 and 2 are still on it after 20000 / 6000 / 6000 steps, in f32 mode as in bf16.  The CPU restatement
+of the reference's step shows the same plateau (tests/test_gpu_trajectory.py)."""
 import math
 import os
 import sys
@@ -19,8 +21,10 @@ from cvae_gan_amd.engine import Engine  # noqa: E402
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-5
+    dtype = torch.float32 if len(sys.argv) > 3 and sys.argv[3] == "f32" else torch.bfloat16
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     P, y, z, B = 64, 100, 32, 256
-    eng = Engine(P, y, z, B, dtype=torch.bfloat16, seed=0)
+    eng = Engine(P, y, z, B, dtype=dtype, seed=seed)
     g = torch.Generator(device="cuda").manual_seed(0)
     lin = torch.linspace(-1, 1, P, device="cuda")
     yy, xx = torch.meshgrid(lin, lin, indexing="ij")
