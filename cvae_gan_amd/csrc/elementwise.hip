@@ -23,6 +23,7 @@ struct RedArgs {
     const float* gamma;  // BNBWD without y
     const float* beta;
     float* ws;           // partials [2][nblk][C]
+    float* shift_out;    // STATS: [C] receives the shift the sums are taken about (row 0), or null
     int M, C, ld, nblk;
     int Cb;              // columns handled per blockIdx.y (== C unless C > 1024; the last block may be ragged)
 };
@@ -50,6 +51,19 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
             if (from_x) { sc[j] = a.gamma[c] * istd[j]; sh[j] = a.beta[c] - mean[j] * sc[j]; }   // as bn_act_fwd
         }
     }
+    // STATS sums are taken about row 0 (sum of (x - x0), sum of (x - x0)^2): E[x^2] - mean^2 over raw values loses
+    // log2(mean^2 / var) bits, which a small batch behind a large mean turns into percent-level errors of the
+    // BatchNorm backward pass ((1 - xhat^2) is eps / var there)
+    float shift[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) shift[j] = 0.f;
+    if (MODE == RED_STATS && a.shift_out && col_ok) {
+        load8<T>((const T*)a.x + c_off + chunk * 8, shift);
+        if (blockIdx.x == 0 && rl == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a.shift_out[c_off + chunk * 8 + j] = shift[j];
+        }
+    }
     if (rl < RL && col_ok) {
         // two rows per trip: their loads are issued together (twice the bytes in flight per thread),
         // the sums are taken in row order, so the result does not depend on the pairing
@@ -64,7 +78,7 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
         auto add = [&](float (&v)[8], float (&d)[8], float (&o)[8]) {
             if (MODE == RED_STATS) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * v[j]; }
+                for (int j = 0; j < 8; ++j) { const float d0 = v[j] - shift[j]; s0[j] += d0; s1[j] += d0 * d0; }
             } else if (MODE == RED_SUM) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s0[j] += v[j];
@@ -137,16 +151,19 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ ws, int n
     ss = wave_sum_d(b);
 }
 
+// shift: [C] the value the sums were taken about, or null (raw sums).  It may alias stats + C (the
+// statistics kernel parks it there): each channel's thread reads it before it writes the inverse deviation.
 __global__ void __launch_bounds__(256) stats_finalize(const float* __restrict__ ws, int nblk, int M, int C,
-                                                      float* __restrict__ stats, float* running_mean,
-                                                      float* running_var, long long* nbt) {
+                                                      float* stats, float* running_mean,
+                                                      float* running_var, long long* nbt, const float* shift) {
     const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     double s, ss;
     sum_partials(ws, nblk, C, c, s, ss, true);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     if ((threadIdx.x & 63) != 0 || c >= C) return;
-    const double mean = s / M;
-    double var = ss / M - mean * mean;
+    const double dm = s / M;
+    const double mean = dm + (shift ? (double)shift[c] : 0.0);
+    double var = ss / M - dm * dm;
     if (var < 0.0) var = 0.0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
@@ -1123,10 +1140,12 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     CVG_CHECK(x && stats && ws, "bn_stats: null");
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
-    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, Cb), Cb};
+    static const bool raw_sums = getenv("CVG_BN_RAW_SUMS") != nullptr;       // A/B switch: sums about 0
+    float* shift = raw_sums ? nullptr : stats + C;      // parked in the slot the finalize overwrites last
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, shift, M, C, C, red_blocks(M, Cb), Cb};
     DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
+    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt, shift);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -1135,7 +1154,7 @@ int cvg_bn_stats_finalize(const float* partials, int32_t nblk, int32_t M, int32_
                           float* running_var, int64_t* nbt, cvg_stream stream) {
     CVG_CHECK(partials && stats && nblk > 0 && M > 0 && C > 0, "bn_stats_finalize: bad args");
     stats_finalize<<<grid1(C, FIN_CH), 256, 0, (hipStream_t)stream>>>(partials, nblk, M, C, stats, running_mean, running_var,
-                                                                      (long long*)nbt);
+                                                                      (long long*)nbt, nullptr);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -1173,10 +1192,10 @@ int cvg_bn_stats_static(const void* x, int32_t dtype, int32_t M, int32_t C, floa
     hipStream_t s = (hipStream_t)stream;
     // every partial [which][block][channel] that stats_finalize reads is written by colreduce first, so
     // nothing left in the array by an earlier call is ever read: no clearing needed
-    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, C, red_blocks(M, C), C};
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, stats + C, M, C, C, red_blocks(M, C), C};
     DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, 1), red_threads(C), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt);
+    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt, stats + C);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -1215,7 +1234,7 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
     CVG_CHECK(dy && x && dx && stats && gamma && dgamma && dbeta && ws, "bn_act_bwd: null");
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
-    RedArgs a = {x, dy, y, stats, gamma, beta, ws, M, C, C, red_blocks(M, Cb), Cb};
+    RedArgs a = {x, dy, y, stats, gamma, beta, ws, nullptr, M, C, C, red_blocks(M, Cb), Cb};
     const int gate = y ? 0 : (beta ? 1 : 2);     // no y and no beta: dy is already gated
     const dim3 rgrid(a.nblk, ceil_div(C, Cb));
     if (gate == 0) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<rgrid, red_threads(Cb), 0, s>>>(a));
@@ -1243,7 +1262,7 @@ int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, f
     CVG_CHECK(x && out && ws && ld >= C && ld % 8 == 0 && md > 0, "colsum: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
-    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, ld, red_blocks(M, Cb), Cb};
+    RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, nullptr, M, C, ld, red_blocks(M, Cb), Cb};
     DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
     sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);

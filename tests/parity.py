@@ -248,3 +248,32 @@ def worst_grads(res):
     we = max(res["grads"].items(), key=lambda kv: kv[1][0])
     wc = min(res["grads"].items(), key=lambda kv: kv[1][1])
     return (we[0], we[1][0]), (wc[0], wc[1][1])
+
+
+def bf16_storage_response(name, step=0, state_fn=None):
+    """How far bf16 STORAGE alone moves each gradient of the f32 computation: the oracle is run a second
+    time with its weights and input image rounded to bf16 and compared with its own exact run.
+    -> {(kind, key): cosine}.  A gradient that this rounding already turns (cosine well below 1) is not a
+    meaningful direction to hold a bf16 implementation to: the engine rounds every activation as well."""
+    case = Case(name)
+
+    def rounded(state):
+        e, d = state
+        for sd in (e, d):
+            for k in sd:
+                if not O.is_buffer(k):
+                    sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
+        return e, d
+
+    st = state_fn(case.init_state()) if state_fn else case.init_state()
+    st_q = rounded(state_fn(case.init_state()) if state_fn else case.init_state())
+    x, labels, eps, mask = case.inputs(step)
+    args = (labels, eps, mask, case.y, case.z, case.P, case.bs_flag, case.n_stage)
+    ref = oracle_pass_raw(st[0], st[1], x, *args)
+    refq = oracle_pass_raw(st_q[0], st_q[1], x.to(torch.bfloat16).to(torch.float32), *args)
+    out = {}
+    for k, t in ref["agrads"].items():
+        out[("dact", k)] = cosine(refq["agrads"][k], t)
+    for k, t in ref["pgrads"].items():
+        out[("grad", k)] = cosine(refq["pgrads"][k], t)
+    return out

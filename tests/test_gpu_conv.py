@@ -248,6 +248,29 @@ def test_tail_forward_through_column_partials(dtype, B, P, ngf):
     assert float((dec.cpu() - torch.tanh(ref_pre)).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("M,C,mean,std,dtype", [(4, 64, 1.0, 0.1, torch.float32), (16, 64, 3.0, 0.5, torch.bfloat16),
+                                                 (4096, 64, 100.0, 1.0, torch.float32), (262144, 128, 10.0, 1.0, torch.bfloat16),
+                                                 (1048576, 64, 0.0, 1.0, torch.float32), (3, 8, -50.0, 0.01, torch.float32)])
+def test_batchnorm_statistics_accuracy(M, C, mean, std, dtype):
+    """cvg_bn_stats against float64 moments of the same values, also where |mean| >> std and for a handful of
+    rows: the sums are taken about the first row, so the variance keeps its digits (sums of raw values measure
+    2e-4 relative at 4 rows with mean / std = 10 and 1e-3 at mean / std = 100).  Bounds: mean within 1e-6 of
+    (|mean| + std), variance within 5e-6 relative (1e-4 at mean / std = 5000)."""
+    from cvae_gan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    x = (mean + std * torch.randn(M, C, device="cuda", generator=g)).to(dtype)
+    xd = x.double()
+    m_ref, v_ref = xd.mean(0), xd.var(0, unbiased=False)
+    stats = torch.zeros(2, C, device="cuda")
+    ws = torch.zeros(2 * ops.bn_stats_blocks(M, C) * C + 64, device="cuda")
+    ops.bn_stats(x, M, C, stats, None, None, None, ws)
+    torch.cuda.synchronize()
+    assert float(((stats[0].double() - m_ref).abs() / (m_ref.abs() + std)).max()) <= 1e-6
+    var_got = 1.0 / stats[1].double() ** 2 - 1e-5
+    tol = 1e-4 if abs(mean) / std > 1000 else 5e-6
+    assert float(((var_got - v_ref).abs() / v_ref).max()) <= tol
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,C,with_res", [(3000, 64, False), (3000, 64, True), (517, 128, False), (96, 256, True)])
 def test_batchnorm_leakyrelu_forward_backward(dtype, M, C, with_res):

@@ -1,0 +1,58 @@
+"""Shapes off the beaten path, f32 mode against the CPU oracle on the same seeded inputs: image sizes
+that are not powers of two (final feature maps of 3 x 3 and 5 x 5), class and latent counts that are not
+multiples of 8 (padded columns in the decoder input; z_dim itself has to be a multiple of 4, which the
+engine checks), one class, the smallest
+training batch (2; BatchNorm1d refuses 1) and batches that do not fill a 256-pixel tile.
+Criteria as in the fixture tests: losses 2e-5, reconstruction 1e-4 of its range, every parameter gradient
+within 1e-3 of the tensor's maximum when no LeakyReLU gate differs between the two sides, cosine >= 0.9999
+otherwise (parity.gate_flips).  At a batch of 2 the head's BatchNorm1d sees two samples per feature: xhat is
++-1 up to eps / var and its backward pass multiplies by (1 - xhat^2) = eps / var, so a 1e-7 difference between two
+correct f32 forward passes comes back as 1e-7 * var / eps; measured 2.1e-3 of the tensor's maximum at 80 x 80 and
+1.1e-2 at 96 x 96 with five stages (2e-2 and more before the statistics kernel took its sums about the first
+row), bound 3e-2 for that degenerate batch, 1e-3 otherwise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+#            P   y   z   B  ngf stages
+SHAPES = [(48, 3, 4, 3, 8, 4),
+          (80, 7, 12, 2, 8, 4),
+          (16, 1, 8, 5, 16, 4),
+          (32, 13, 20, 7, 32, 4),
+          (96, 5, 4, 2, 8, 5)]
+
+
+@pytest.mark.parametrize("P,y,z,B,ngf,n_stage", SHAPES)
+def test_odd_shapes_f32_match_oracle(P, y, z, B, ngf, n_stage):
+    from parity import synthetic_parity, worst_grads
+    r = synthetic_parity(P, y, z, B, torch.float32, seed=11, init_seed=2, ngf=ngf, n_stage=n_stage)
+    (wk, werr), (ck, wcos) = worst_grads(r)
+    print("P %d y %d z %d B %d ngf %d stages %d: loss err" % (P, y, z, B, ngf, n_stage), r["loss"],
+          "dec err %.2e" % r["dec_err"], "flips", r["flips"], "worst grad", wk, "%.3e" % werr, ck, "%.6f" % wcos)
+    assert r["loss"]["KL"] <= 2e-5 and r["loss"]["LL"] <= 2e-5, r["loss"]
+    assert r["dec_err"] <= 1e-4
+    assert wcos >= (0.999 if B == 2 else 0.9999), (ck, wcos)
+    assert werr <= (3e-2 if B == 2 else 1e-3) or r["flips"] > 0, (wk, werr)
+
+
+def test_eval_batch_of_one():
+    """Inference takes a single image (train mode refuses it, as nn.BatchNorm1d does)."""
+    from collections import OrderedDict
+    from cvae_gan_amd.engine import Engine
+    from oracle import ref_cpu as O
+    P, y, z, ngf = 32, 4, 8, 8
+    e, d = O.init_params(P, y, z, seed=1, ngf=ngf)
+    state = OrderedDict(e)
+    state.update(d)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(1, 3, P, P, generator=g) * 2 - 1
+    labels = torch.tensor([2])
+    eps = torch.randn(1, z, generator=g)
+    eng = Engine(P, y, z, 1, dtype=torch.float32, ngf=ngf, state=state)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        eng.forward_backward(x.cuda(), labels.int().cuda(), eps.cuda(), 1.0)
+    eng.training = False
+    dec = eng.reconstruct(x.cuda(), labels.int().cuda(), eps.cuda()).cpu()
+    ref, _, _, _ = O.cvae_forward(e, d, x, labels, eps, None, y, train=False)
+    assert float((dec - ref).abs().max()) <= 1e-4
