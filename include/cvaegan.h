@@ -185,7 +185,10 @@ int cvg_pack_image(const float* x, void* xpad, int32_t B, int32_t P, int32_t dty
  * mode, networks.py:174, :235, :238, :188).  Writes stats = {mean[C], invstd[C]} and,
  * if running_mean != NULL, updates running_mean / running_var (momentum 0.1,
  * unbiased variance) and increments *num_batches_tracked (int64).
- * ws: f32 [2][nblk][C] partials with nblk = cvg_bn_stats_blocks(M, C).              */
+ * ws: f32 [2][nblk][C] partials with nblk = cvg_bn_stats_blocks(M, C).
+ * The sums are taken about row 0 (sum of (x - x0), sum of (x - x0)^2), so the variance does
+ * not lose digits when |mean| >> std or M is a handful of rows; between the two kernels of the
+ * call the invstd half of `stats` holds x0.                                         */
 int32_t cvg_bn_stats_blocks(int32_t M, int32_t C);
 int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
                  float* running_mean, float* running_var, int64_t* num_batches_tracked,
