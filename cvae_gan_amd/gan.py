@@ -172,7 +172,8 @@ class CVAEGAN:
         return out
 
     def read_losses(self):
-        kl, ll = self.vae.losses[:2].tolist()
+        vae = self.vae.read_losses()         # raises if a class label outside [0, y) reached the encoder
+        kl, ll = vae["KL"], vae["LL"]
         ld, lgd, lpd = self.D.losses.tolist()
         lc, lgc, lpc = self.C.losses.tolist()
         return dict(KL=kl, LL=ll, D=ld, C=lc, GD=lgd, GC=lgc, PD=lpd, PC=lpc)
