@@ -81,8 +81,8 @@ def _load():
         "cvg_bn_act_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "cvg_colsum": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
         "cvg_permute_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
-        "cvg_reparam_kl_fwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
-        "cvg_reparam_kl_bwd": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
+        "cvg_reparam_kl_fwd": (C.c_int, [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
+        "cvg_reparam_kl_bwd": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp]),
         "cvg_labels_prepare": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "cvg_lrelu_dropout_fwd": (C.c_int, [vp, vp, vp, i32, i64, vp]),
         "cvg_lrelu_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i32, i64, vp]),

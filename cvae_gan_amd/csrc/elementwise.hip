@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256) label_bias_scatter(const float* __restric
 
 // ---- reparameterisation + KL -----------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(1024) reparam_kl_fwd(const T* __restrict__ h, const float* __restrict__ eps,
+__global__ void __launch_bounds__(1024) reparam_kl_fwd(const T* __restrict__ h, int h_ld, const float* __restrict__ eps,
                                                        const int* __restrict__ labels, int B, int z, int y_dim,
                                                        int zin_ld, T* __restrict__ zin, float* __restrict__ z_mean,
                                                        float* __restrict__ z_sigma, float* __restrict__ kl,
@@ -663,8 +663,8 @@ __global__ void __launch_bounds__(1024) reparam_kl_fwd(const T* __restrict__ h, 
             mu[u] = ls[u] = ep[u] = 0.f;
             if (i < n) {
                 const int b = i / z, j = i - b * z;
-                mu[u] = to_f32(h[(size_t)b * 2 * z + j]);
-                ls[u] = to_f32(h[(size_t)b * 2 * z + z + j]);
+                mu[u] = to_f32(h[(size_t)b * h_ld + j]);
+                ls[u] = to_f32(h[(size_t)b * h_ld + z + j]);
                 ep[u] = eps[i];
             }
         }
@@ -700,7 +700,7 @@ template <typename T>
 __global__ void reparam_kl_bwd(const T* __restrict__ dzin, int zin_ld, const float* __restrict__ eps,
                                const float* __restrict__ z_mean, const float* __restrict__ z_sigma,
                                const float* __restrict__ g_mean, const float* __restrict__ g_sigma, float kl_scale,
-                               float batch_size, int B, int z, T* __restrict__ dh) {
+                               float batch_size, int B, int z, T* __restrict__ dh, int h_ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * z) return;
     const int b = i / z, j = i % z;
@@ -712,8 +712,8 @@ __global__ void reparam_kl_bwd(const T* __restrict__ dzin, int zin_ld, const flo
     if (g_mean) dmu += g_mean[i];
     if (g_sigma) dsg += g_sigma[i];
     const float dls = dsg * sg + (2.f * sg * sg - 2.f) * s;
-    dh[(size_t)b * 2 * z + j] = from_f32<T>(dmu);
-    dh[(size_t)b * 2 * z + z + j] = from_f32<T>(dls);
+    dh[(size_t)b * h_ld + j] = from_f32<T>(dmu);
+    dh[(size_t)b * h_ld + z + j] = from_f32<T>(dls);
 }
 
 // ---- class indices: copy, keep inside [0, n_class), flag the ones that were not --------------------
@@ -1297,12 +1297,12 @@ int cvg_label_bias_bwd(const void* dy, int32_t dtype, const int32_t* labels, int
     return 0;
 }
 
-int cvg_reparam_kl_fwd(const void* h, int32_t dtype, const float* eps, const int32_t* labels, int32_t B, int32_t z,
-                       int32_t y_dim, int32_t zin_ld, void* zin, float* z_mean, float* z_sigma, float* kl,
+int cvg_reparam_kl_fwd(const void* h, int32_t dtype, int32_t h_ld, const float* eps, const int32_t* labels, int32_t B,
+                       int32_t z, int32_t y_dim, int32_t zin_ld, void* zin, float* z_mean, float* z_sigma, float* kl,
                        float batch_size, cvg_stream stream) {
     CVG_CHECK(h && eps && labels && zin && z_mean && z_sigma && kl, "reparam_kl_fwd: null");
-    CVG_CHECK(zin_ld >= z + y_dim && zin_ld % 8 == 0 && B > 0 && z > 0, "reparam_kl_fwd: bad dims");
-    DISPATCH(dtype, reparam_kl_fwd<T><<<1, 1024, 0, (hipStream_t)stream>>>((const T*)h, eps, labels, B, z, y_dim, zin_ld,
+    CVG_CHECK(zin_ld >= z + y_dim && zin_ld % 8 == 0 && B > 0 && z > 0 && h_ld >= 2 * z, "reparam_kl_fwd: bad dims");
+    DISPATCH(dtype, reparam_kl_fwd<T><<<1, 1024, 0, (hipStream_t)stream>>>((const T*)h, h_ld, eps, labels, B, z, y_dim, zin_ld,
                                                                           (T*)zin, z_mean, z_sigma, kl, batch_size));
     CVG_LAUNCH_CHECK();
     return 0;
@@ -1310,10 +1310,10 @@ int cvg_reparam_kl_fwd(const void* h, int32_t dtype, const float* eps, const int
 
 int cvg_reparam_kl_bwd(const void* dzin, int32_t dtype, int32_t zin_ld, const float* eps, const float* z_mean,
                        const float* z_sigma, const float* g_mean, const float* g_sigma, float kl_scale,
-                       float batch_size, int32_t B, int32_t z, void* dh, cvg_stream stream) {
-    CVG_CHECK(dzin && eps && z_mean && z_sigma && dh && B > 0 && z > 0, "reparam_kl_bwd: bad args");
+                       float batch_size, int32_t B, int32_t z, void* dh, int32_t h_ld, cvg_stream stream) {
+    CVG_CHECK(dzin && eps && z_mean && z_sigma && dh && B > 0 && z > 0 && h_ld >= 2 * z, "reparam_kl_bwd: bad args");
     DISPATCH(dtype, reparam_kl_bwd<T><<<grid1((int64_t)B * z), 256, 0, (hipStream_t)stream>>>(
-                        (const T*)dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, (T*)dh));
+                        (const T*)dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, (T*)dh, h_ld));
     CVG_LAUNCH_CHECK();
     return 0;
 }

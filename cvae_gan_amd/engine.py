@@ -254,7 +254,7 @@ class Engine:
         (y_dim may then be 0: no label planes); extra_params: {name: shape} of further trainable
         tensors in the same arenas; stem_input_grad: also plan the gradient w.r.t. the image."""
         assert pix_dim % (2 ** n_stage) == 0, "pix_dim must be a multiple of %d" % (2 ** n_stage)
-        assert z_dim % 4 == 0, "z_dim must be a multiple of 4 (channel vectors are 8 wide)"
+        assert z_dim >= 2 and z_dim % 2 == 0, "z_dim must be even (the head's 4 * z_dim features are handled 8 at a time)"
         assert ngf % 8 == 0 and (ngf & (ngf - 1)) == 0, "ngf must be a power of two >= 8"
         self.P, self.y, self.z, self.B = pix_dim, y_dim, z_dim, batch
         self.dtype, self.ngf, self.n_stage = dtype, ngf, n_stage
@@ -453,22 +453,26 @@ class Engine:
             H //= 2
         s, C = self.s, stage_channels(self.n_stage, ngf)[-1][1]
         fin, fcd, nz = s * s * C, 4 * self.z, 2 * self.z
-        e["fin"], e["fcd"], e["nz"], e["C_last"] = fin, fcd, nz, C
+        nz_ld = _rup(nz, 8)              # row pitch of h / dh: padded when 2 * z_dim is not a multiple of 8
+        e["fin"], e["fcd"], e["nz"], e["nz_ld"], e["C_last"] = fin, fcd, nz, nz_ld, C
         # Linear layers as 1x1 "convolutions" over a 1x1 image; the flatten order of the
         # reference is (c, h, w), ours (h, w, c): the weight maps carry the permutation.
         e["fc0"] = _Gemm(self, _desc(T, B, 1, 1, fin, 1, 1, fcd, 1, 1),
                          _wmap(1, fin, 0, C, 1, s * s, fcd, C, s * s), EP + "fc.0.weight")
         e["fc0_dg"] = _Gemm(self, _desc(T, B, 1, 1, fcd, 1, 1, fin, 1, 1),
                             _wmap(C, 1, s * s, fcd, 0, fin, fin, fcd, 1), EP + "fc.0.weight")
-        e["fc3"] = _Gemm(self, _desc(T, B, 1, 1, fcd, 1, 1, nz, 1, 1),
+        e["fc3"] = _Gemm(self, _desc(T, B, 1, 1, fcd, 1, 1, nz_ld, 1, 1),
                          _wmap(1, fcd, 0, fcd, 0, 1, nz, fcd, 1), EP + "fc.3.weight")
-        e["fc3_dg"] = _Gemm(self, _desc(T, B, 1, 1, nz, 1, 1, fcd, 1, 1),
-                            _wmap(1, 1, 0, nz, 0, fcd, fcd, nz, 1), EP + "fc.3.weight")
+        e["fc3_dg"] = _Gemm(self, _desc(T, B, 1, 1, nz_ld, 1, 1, fcd, 1, 1),
+                            _wmap(1, 1, 0, nz_ld, 0, fcd, fcd, nz, 1), EP + "fc.3.weight")
         e["f0"], e["f1"] = self._t(B, fcd), self._t(B, fcd)
         e["d_f0"], e["d_f1"] = self._t(B, fcd), self._t(B, fcd)
         e["stf"] = self._f(2, fcd)
-        e["h"] = self._t(B, nz)
-        e["dh"] = self._t(B, nz)
+        e["h"] = self._t(B, nz_ld)         # columns from nz on: the padded bias (zero), never read
+        e["dh"] = self._t(B, nz_ld)        # columns from nz on stay zero
+        # padded copies of the head bias / its gradient when the rows are (the kernels read N = nz_ld entries)
+        e["bias_h"] = self._f(nz_ld) if nz_ld != nz else None
+        e["bgrad_h"] = self._f(nz_ld) if nz_ld != nz else None
         e["labels"] = torch.zeros(B, dtype=torch.int32, device=self.device)
 
     def _build_decoder(self):
@@ -603,6 +607,8 @@ class Engine:
         self._pack_batch.run()
         if self.y > 0:
             ops.label_bias(self.params[EP + "conv.1.weight"], self.enc["cbias"], self.ngf, self.y)
+        if getattr(self, "enc", None) and self.enc.get("bias_h") is not None:
+            ops.permute_f32(self.params[EP + "fc.3.bias"], self.enc["bias_h"], self.enc["nz"])
         d = self.dec
         if d is not None:
             ops.permute_f32(self.params[DP + "fc.0.bias"], d["bias0"], d["F"])
@@ -751,7 +757,7 @@ class Engine:
             xin = blk["out"]
         self._fwd(e["fc0"], xin, e["f0"], bias=self.params[EP + "fc.0.bias"])
         self._bn(e["f0"], None, e["f1"], B, e["fcd"], e["stf"], EP + "fc.1")
-        self._fwd(e["fc3"], e["f1"], e["h"], bias=self.params[EP + "fc.3.bias"])
+        self._fwd(e["fc3"], e["f1"], e["h"], bias=e["bias_h"] if e["bias_h"] is not None else self.params[EP + "fc.3.bias"])
         return e["h"]
 
     def enc_backward(self, dh, param_grads=True, input_grad=False, part=None):
@@ -803,9 +809,12 @@ class Engine:
         frozen = self._frozen
         last = e["blocks"][-1]
         with self._branch():
-            self._wgrad(e["fc3"], e["f1"], dh, e["nz"])
-            if not frozen:
+            self._wgrad(e["fc3"], e["f1"], dh, e["nz_ld"])
+            if not frozen and e["bgrad_h"] is None:
                 ops.colsum(dh, B, e["nz"], e["nz"], self.grads[EP + "fc.3.bias"], self.red_ws_side)
+            elif not frozen:
+                ops.colsum(dh, B, e["nz_ld"], e["nz_ld"], e["bgrad_h"], self.red_ws_side)
+                ops.permute_f32(e["bgrad_h"], self.grads[EP + "fc.3.bias"], e["nz"])
         self._fwd(e["fc3_dg"], dh, e["d_f1"])
         self._bn_bwd(e["d_f1"], None, e["f0"], e["d_f0"], B, e["fcd"], e["stf"], EP + "fc.1")
         with self._branch():
@@ -859,12 +868,12 @@ class Engine:
     def sample(self, h, eps, batch_size):
         d = self.dec
         ops.reparam_kl_fwd(h, eps, self.enc["labels"], self.B, self.z, self.y, d["zin_ld"], d["zin"],
-                           self.z_mean, self.z_sigma, self.losses[0:1], batch_size)
+                           self.z_mean, self.z_sigma, self.losses[0:1], batch_size, h_ld=self.enc["nz_ld"])
         return d["zin"]
 
     def sample_backward(self, dzin, eps, g_mean, g_sigma, kl_scale, batch_size):
         ops.reparam_kl_bwd(dzin, self.dec["zin_ld"], eps, self.z_mean, self.z_sigma, g_mean, g_sigma,
-                           kl_scale, batch_size, self.B, self.z, self.enc["dh"])
+                           kl_scale, batch_size, self.B, self.z, self.enc["dh"], h_ld=self.enc["nz_ld"])
         return self.enc["dh"]
 
     def set_decoder_input(self, z, y_vec):

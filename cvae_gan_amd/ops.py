@@ -173,14 +173,17 @@ def permute_f32(src, out, n, d=1, a=1, b=0):
     check(lib.cvg_permute_f32(ptr(src), ptr(out), n, d, a, b, stream()))
 
 
-def reparam_kl_fwd(h, eps, labels, B, z, y_dim, zin_ld, zin, z_mean, z_sigma, kl, batch_size):
-    check(lib.cvg_reparam_kl_fwd(ptr(h), dt(h), ptr(eps), ptr(labels), B, z, y_dim, zin_ld, ptr(zin),
+def reparam_kl_fwd(h, eps, labels, B, z, y_dim, zin_ld, zin, z_mean, z_sigma, kl, batch_size, h_ld=None):
+    """h_ld: row pitch of h (default: its second dimension)."""
+    h_ld = h.shape[-1] if h_ld is None else h_ld
+    check(lib.cvg_reparam_kl_fwd(ptr(h), dt(h), h_ld, ptr(eps), ptr(labels), B, z, y_dim, zin_ld, ptr(zin),
                                  ptr(z_mean), ptr(z_sigma), ptr(kl), float(batch_size), stream()))
 
 
-def reparam_kl_bwd(dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, dh):
+def reparam_kl_bwd(dzin, zin_ld, eps, z_mean, z_sigma, g_mean, g_sigma, kl_scale, batch_size, B, z, dh, h_ld=None):
+    h_ld = dh.shape[-1] if h_ld is None else h_ld
     check(lib.cvg_reparam_kl_bwd(ptr(dzin), dt(dzin), zin_ld, ptr(eps), ptr(z_mean), ptr(z_sigma), ptr(g_mean),
-                                 ptr(g_sigma), float(kl_scale), float(batch_size), B, z, ptr(dh), stream()))
+                                 ptr(g_sigma), float(kl_scale), float(batch_size), B, z, ptr(dh), h_ld, stream()))
 
 
 def labels_prepare(labels, out, n, n_class, bad):

@@ -64,12 +64,15 @@ _IMPL = Library("cvaegan", "IMPL", "CUDA")
 def _encoder_forward(engine, x, labels):
     eng = _engine(engine)
     eng.params_changed()                 # an outside optimiser may have stepped
-    return eng.enc_forward(x.contiguous().float(), labels).float()
+    return eng.enc_forward(x.contiguous().float(), labels)[:, :eng.enc["nz"]].float()
 
 
 def _encoder_backward(engine, dh):
     eng = _engine(engine)
-    ops.cast(dh.contiguous().float(), eng.enc["dh"], dh.numel())
+    if eng.enc["nz_ld"] == eng.enc["nz"]:
+        ops.cast(dh.contiguous().float(), eng.enc["dh"], dh.numel())
+    else:                                # padded rows: the columns from 2 * z_dim on stay zero
+        eng.enc["dh"][:, :eng.enc["nz"]].copy_(dh)
     eng.enc_backward(eng.enc["dh"])
 
 

@@ -257,25 +257,27 @@ int cvg_permute_f32(const float* in, float* out, int32_t n, int32_t d, int32_t a
                     cvg_stream s);
 
 /* CVAE_T._sample_latent + latent_loss (networks.py:24-47, cvae.py:137), fused.
- *   h      [B][2z] (dtype) encoder head output
+ *   h      [B][h_ld] (dtype) encoder head output: mean in columns [0, z), log sigma in [z, 2z);
+ *          h_ld >= 2z (rows padded to the 8-element vector width when 2z is not a multiple of 8)
  *   eps    f32 [B][z]
  *   labels int32 [B]
  *   zin    [B][zin_ld] (dtype): z, then the one-hot label, then zeros (decoder input,
  *          networks.py:64)
  *   z_mean, z_sigma  f32 [B][z]
  *   kl     f32 scalar: mean(mu^2 + sigma^2 - log sigma^2 - 1) / batch_size         */
-int cvg_reparam_kl_fwd(const void* h, int32_t dtype, const float* eps, const int32_t* labels,
-                       int32_t B, int32_t z, int32_t y_dim, int32_t zin_ld, void* zin,
+int cvg_reparam_kl_fwd(const void* h, int32_t dtype, int32_t h_ld, const float* eps,
+                       const int32_t* labels, int32_t B, int32_t z, int32_t y_dim, int32_t zin_ld, void* zin,
                        float* z_mean, float* z_sigma, float* kl, float batch_size,
                        cvg_stream s);
 /* dh[:, :z] = dz + g_mean + kl_scale*2*mu/(B*z*batch)
  * dh[:, z:] = (dz*eps + g_sigma)*sigma + kl_scale*(2*sigma^2 - 2)/(B*z*batch)
  * dz is read from dzin[B][zin_ld] (dtype); g_mean / g_sigma (f32, may be NULL) are
- * gradients that arrive through the exposed z_mean / z_sigma tensors.              */
+ * gradients that arrive through the exposed z_mean / z_sigma tensors.  dh is [B][h_ld];
+ * columns from 2z on are left as they are (the caller keeps them zero).             */
 int cvg_reparam_kl_bwd(const void* dzin, int32_t dtype, int32_t zin_ld, const float* eps,
                        const float* z_mean, const float* z_sigma, const float* g_mean,
                        const float* g_sigma, float kl_scale, float batch_size, int32_t B,
-                       int32_t z, void* dh, cvg_stream s);
+                       int32_t z, void* dh, int32_t h_ld, cvg_stream s);
 
 /* Class indices as the kernels use them: out[i] = labels[i] kept inside [0, n_class); *bad is set to
  * 1.0f when any index was outside (it is never cleared here: the caller reads and clears it when it

@@ -128,8 +128,9 @@ def engine_tensors(eng):
             agrads["blk%d.%s" % (i, n)] = nchw(blk["d_" + n], B, H, H, C)
         acts["blk%d.out" % i] = nchw(blk["out"], B, H // 2, H // 2, Co)
         agrads["blk%d.out" % i] = nchw(blk["d_out"], B, H // 2, H // 2, Co)
-    acts["f0"], acts["f1"], acts["h"] = e["f0"].float().cpu(), e["f1"].float().cpu(), e["h"].float().cpu()
-    agrads["f0"], agrads["f1"], agrads["h"] = e["d_f0"].float().cpu(), e["d_f1"].float().cpu(), e["dh"].float().cpu()
+    nz = e["nz"]
+    acts["f0"], acts["f1"], acts["h"] = e["f0"].float().cpu(), e["f1"].float().cpu(), e["h"].float().cpu()[:, :nz]
+    agrads["f0"], agrads["f1"], agrads["h"] = e["d_f0"].float().cpu(), e["d_f1"].float().cpu(), e["dh"].float().cpu()[:, :nz]
     F = d["F"]
     acts["g0"], acts["g1"] = d["g0"].float().cpu()[:, :F], d["g1"].float().cpu()[:, :F]
     agrads["g0"], agrads["g1"] = d["d_g0"].float().cpu()[:, :F], d["d_g1"].float().cpu()[:, :F]
@@ -233,7 +234,7 @@ def synthetic_parity(P, Y, Z, B, dtype, seed=3, init_seed=5, ngf=64, n_stage=4, 
     acts, _, _ = engine_tensors(eng)
     out = {"loss": {k: abs(got[k] - float(ref["losses"][k])) / max(abs(float(ref["losses"][k])), 1e-3) for k in ("KL", "LL")},
            "dec_err": float((dec.cpu() - ref["dec"]).abs().max()), "dec_cos": cosine(dec.cpu(), ref["dec"]),
-           "h_cos": cosine(eng.enc["h"].float().cpu(), ref["h_enc"]), "grads": {}, "eng": eng, "ref": ref,
+           "h_cos": cosine(eng.enc["h"].float().cpu()[:, :eng.enc["nz"]], ref["h_enc"]), "grads": {}, "eng": eng, "ref": ref,
            "flips": gate_flips(ref["acts"], acts)}
     del acts
     for k, gref in ref["pgrads"].items():

@@ -122,3 +122,37 @@ def test_module_surface_runs_through_torch_custom_ops(monkeypatch):
     assert all(torch.equal(u, v) for u, v in zip(a, b)) and not torch.equal(a[0], p0)
     with pytest.raises(NotImplementedError):                  # no CPU implementation: no silent other path
         torch.ops.cvaegan.adamw(p0.cpu(), grad.cpu(), p0.cpu(), p0.cpu(), 1e-3, 0.5, 0.999, 1e-8, 0.01, 1)
+
+
+def test_module_surface_with_z_dim_off_the_vector_width():
+    """z_dim = 10: the head's rows hold 20 values and are padded to 24 inside the engine; the module surface
+    still hands torch [B, 2z] tensors and takes [B, 2z] gradients.  z_mean / z_sigma (which depend on no random
+    draw) against the oracle in f32, gradients finite and of the reference's shapes."""
+    from cvae_gan_amd import networks as N
+    from oracle import ref_cpu as O
+    P, y, z, B, ngf = 32, 6, 10, 5, 8
+    a = Args()
+    a.z_dim, a.y_dim, a.pix_dim, a.device, a.dtype, a.ngf = z, y, P, torch.device("cuda"), "f32", ngf
+    enc, dec = N.encoder(a), N.decoder(a)
+    e, d = O.init_params(P, y, z, seed=3, ngf=ngf)
+    enc.load_state_dict(e)
+    dec.load_state_dict(d)
+    model = N.CVAE_T(a, enc, dec)
+    model.train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, 3, P, P, generator=g) * 2 - 1
+    labels = torch.randint(0, y, (B,), generator=g)
+    yvec = O.one_hot(labels, y)
+    out = model(x.cuda(), labels.cuda(), yvec.cuda())
+    h_ref = O.encoder_forward(e, x, O.label_planes(labels, y, P), True, {})
+    _, mu, sigma = O.sample_latent(h_ref, torch.zeros(B, z), z)
+    assert tuple(model.z_mean.shape) == (B, z) and tuple(model.z_sigma.shape) == (B, z)
+    assert float((model.z_mean.detach().cpu() - mu).abs().max()) <= 1e-4 * float(mu.abs().max())
+    assert float((model.z_sigma.detach().cpu() - sigma).abs().max()) <= 1e-4 * float(sigma.abs().max())
+    ll = torch.nn.functional.mse_loss(out, x.cuda()) / B * 50
+    kl = N.latent_loss(model.z_mean, model.z_sigma) / B
+    (kl + ll).backward()
+    torch.cuda.synchronize()
+    for k, shape in (("encoder.fc.3.weight", (2 * z, 4 * z)), ("encoder.fc.3.bias", (2 * z,))):
+        gw = enc.state_dict(keep_vars=True)[k].grad
+        assert gw is not None and tuple(gw.shape) == shape and bool(torch.isfinite(gw).all()) and float(gw.abs().max()) > 0, k

@@ -1,7 +1,7 @@
 """Shapes off the beaten path, f32 mode against the CPU oracle on the same seeded inputs: image sizes
 that are not powers of two (final feature maps of 3 x 3 and 5 x 5), class and latent counts that are not
-multiples of 8 (padded columns in the decoder input; z_dim itself has to be a multiple of 4, which the
-engine checks), one class, the smallest
+multiples of 8 (padded columns in the decoder input and, for z_dim = 2 and 10, in the encoder head's output
+rows; z_dim has to be even, which the engine checks), one class, the smallest
 training batch (2; BatchNorm1d refuses 1) and batches that do not fill a 256-pixel tile.
 Criteria as in the fixture tests: losses 2e-5, reconstruction 1e-4 of its range, every parameter gradient
 within 1e-3 of the tensor's maximum when no LeakyReLU gate differs between the two sides, cosine >= 0.9999
@@ -16,8 +16,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 #            P   y   z   B  ngf stages
-SHAPES = [(48, 3, 4, 3, 8, 4),
-          (80, 7, 12, 2, 8, 4),
+SHAPES = [(48, 3, 2, 3, 8, 4),
+          (80, 7, 10, 2, 8, 4),
           (16, 1, 8, 5, 16, 4),
           (32, 13, 20, 7, 32, 4),
           (96, 5, 4, 2, 8, 5)]
