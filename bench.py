@@ -26,6 +26,7 @@ CONFIGS = {
     "c3": (64, 100, 32, 256, 4),
     "c4": (128, 100, 32, 64, 4),
     "c4d": (128, 100, 32, 64, 5),          # "deeper stacks": ndown = nup = 5 (networks.py:165, :133)
+    "cli": (512, 1000, 256, 50, 4),        # the reference's command-line defaults (starter.py:19-27)
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 

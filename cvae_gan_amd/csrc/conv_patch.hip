@@ -1012,9 +1012,14 @@ bool patch_eligible(const cvg_conv_desc* d) {
     if (d->x_pix_pitch != d->Cin && !(d->Cin == CK && d->pad_mode == CVG_PAD_ZERO)) return false;   // overlapping windows: one chunk
     if (!((d->KW == 3 && d->ntaps == 9) || (d->KW == 7 && d->ntaps == 49) || (d->KW == 1 && d->ntaps == 7)))
         return false;                                                                        // instantiated kernels
-    // offsets are 32-bit relative to a workgroup's first image: up to 512 images of a tile must fit
-    if (512ll * d->x_img_pitch >= (1ll << 31) || 512ll * d->y_img_pitch >= (1ll << 31)) return false;
     return true;
+}
+
+// Offsets are 32-bit relative to a workgroup's (or tile's) first image: the TB images of one tile must fit.
+// Tiles of images larger than the tile hold one image (TB = 1), so 256 x 256 and 512 x 512 inputs stay on
+// the patch kernels; only a tile spanning many small images could come near the limit.
+static bool offsets_fit(const cvg_conv_desc* d, int TB) {
+    return (long long)TB * d->x_img_pitch < (1ll << 31) && (long long)TB * d->y_img_pitch < (1ll << 31);
 }
 
 // Smallest number of tiles, then the smallest patch, over all TH x TW <= BM.
@@ -1142,6 +1147,7 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     const char mode = wide ? wide[0] : 'a';
     if (d->dtype == CVG_BF16 && d->N > 64 && mode != '0') p.BM = 256;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW)) return;
+    if (!offsets_fit(d, p.TB)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
     p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
     p.patch_px = p.TB * p.PH * p.PW;
@@ -1244,8 +1250,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     static const bool no_s2 = getenv("CVG_WGRAD_S2_GATHER") != nullptr;      // A/B switch for benchmarking
     if (!no_s2 && d->stride == 2 && d->tstep_y == 1 && d->tstep_x == 1 && d->dtype == CVG_BF16 && d->KW == 3 &&
         d->ntaps == 9 && d->N > 64 && d->Cin % CK == 0 && d->x_pix_pitch == d->Cin && d->pad_mode == CVG_PAD_ZERO &&
-        512ll * d->x_img_pitch < (1ll << 31) && 512ll * d->y_img_pitch < (1ll << 31) &&
-        choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 592, p.TB, p.TH, p.TW, 2)) {
+        choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 592, p.TB, p.TH, p.TW, 2) && offsets_fit(d, p.TB)) {
         // the nine-tap kernel, four waves, one 32-channel chunk per workgroup
         p.KW = 3; p.KH = 3; p.T = 9; p.WN = 4; p.WT = 1; p.BNW = 128;
         p.PH = 2 * p.TH + 1; p.PW = 2 * p.TW + 1;
@@ -1277,7 +1282,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
         const int wc = (d->N > 64 && (no8 || d->Cin % (2 * CK) != 0)) ? 1 : 2;
         const int wn9 = d->N > 64 ? 4 : 2;
         if (d->Cin % (CK * wc) == 0 &&
-            choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 256, p.TB, p.TH, p.TW)) {
+            choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 256, p.TB, p.TH, p.TW) && offsets_fit(d, p.TB)) {
             p.WN = wn9; p.WT = wc; p.BNW = 32 * p.WN;
             p.PH = p.TH + 2; p.PW = p.TW + 2;
             p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
@@ -1308,6 +1313,7 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     if (!(tpw == 5 || tpw == 3 || tpw == 13)) return;                        // instantiated tap counts
     const int bmp = es == 2 ? 256 : 128;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, bmp, 2 * bmp, p.TB, p.TH, p.TW)) return;
+    if (!offsets_fit(d, p.TB)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
     p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
     p.ntiles = p.tiles_y * p.tiles_x * p.groups;

@@ -234,3 +234,24 @@ def test_split_encoder_backward_equals_whole():
     pad = torch.isnan(eng.g_arena)                      # alignment gaps between tensors stay untouched
     assert torch.equal(eng.g_arena[~pad], whole[~pad])
     assert int(pad.sum()) < 64
+
+
+@pytest.mark.parametrize("pix", [256, 512])
+def test_large_images_f32_match_oracle(pix):
+    """256 x 256 and 512 x 512 (the reference's --pix_dim default) at the reference's width, batch 3: a tile of
+    such an image holds one image, so the 32-bit offsets inside a tile fit and every stride-1 layer stays on the
+    patch kernels.  Losses 2e-5, reconstruction 1e-4; with hundreds of thousands of pixels per channel a few
+    dozen LeakyReLU gates sit within rounding of zero (parity.gate_flips), so gradients are held by direction."""
+    from parity import synthetic_parity, worst_grads
+    from cvae_gan_amd import ops
+    r = synthetic_parity(pix, 16, 32, 3, torch.float32, seed=4, init_seed=6)
+    (wk, werr), (ck, wcos) = worst_grads(r)
+    print("P %d f32: loss err" % pix, r["loss"], "dec err %.2e" % r["dec_err"], "flipped gates", r["flips"],
+          "worst grad err", wk, "%.3e" % werr, "worst grad cos", ck, "%.6f" % wcos)
+    kinds = {ops.conv_fwd_kernel(g.desc) for g in r["eng"]._gemms}
+    assert any(k.startswith("patch_fwd") and "64ch" in k for k in kinds), kinds      # the full-resolution layers too
+    assert r["loss"]["KL"] <= 2e-5 and r["loss"]["LL"] <= 2e-5, r["loss"]
+    assert r["dec_err"] <= 1e-4
+    assert r["flips"] <= 256, r["flips"]
+    assert wcos >= 0.9999, (ck, wcos)
+    assert werr <= 5e-3 or r["flips"] > 0, (wk, werr)
