@@ -110,6 +110,12 @@ class CVAE(object):
                                  device=self.device, seed=seed)
         self._sample_engine = None
         self.sync = None
+        # one replica, plain CVAE: after two eager steps the whole step (dropout draw, forward, backward,
+        # AdamW, weight repack) is captured into a HIP graph and replayed on static input buffers
+        # (args.graph = False or CVG_TRAINER_EAGER: eager launches throughout)
+        self._use_graph = (self.world == 1 and self.gan is None and getattr(args, "graph", True)
+                           and os.environ.get("CVG_TRAINER_EAGER") is None)
+        self._graph, self._graph_in, self._graph_out, self._steps_done = None, None, None, 0
         if self.world > 1 and self.gan is not None:
             self.gan.broadcast_state()                            # the three arenas are summed after backward
         elif self.world > 1:
@@ -184,12 +190,35 @@ class CVAE(object):
         loss is scaled by 1/N, so the summed gradients are those of the global-batch mean."""
         eng = self.engine
         if self.sync is None:
-            return eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
+            self._steps_done += 1
+            if not self._use_graph or self._steps_done <= 2:
+                eng.random_mask()
+                return eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
+            return self._replay_step(x, cls, eps)
+        eng.random_mask()
         self.sync.begin_step()
         dec = eng.forward_backward(x, cls, eps, float(self.batch_size), loss_scale=1.0 / self.world)
         self.sync.finish()
         eng.adamw_step(self.lr)
         return dec
+
+    def _replay_step(self, x, cls, eps):
+        eng = self.engine
+        if self._graph is None:
+            self._graph_in = (torch.empty_like(x), torch.empty_like(cls), torch.empty_like(eps))
+            eng.pack_weights(force=True)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng._packed_version = -1             # the captured step repacks the weights it updated last time
+                eng.random_mask()
+                self._graph_out = eng.train_step(*self._graph_in, float(self.batch_size), self.lr)
+            self._graph = graph
+        for dst, src in zip(self._graph_in, (x, cls, eps)):
+            dst.copy_(src)
+        self._graph.replay()
+        eng.params_changed()                         # host-side version: engines that share the weights repack
+        return self._graph_out
 
     def read_losses(self):
         """The losses of the whole (global) batch: the mean of the ranks' values."""
@@ -217,8 +246,8 @@ class CVAE(object):
             it = -1
             for it, (x, cls) in enumerate(self.batches()):
                 eps.normal_(generator=self._eps_gen)
-                eng.random_mask()
                 if self.gan is not None:
+                    eng.random_mask()
                     z_p.normal_(generator=self._eps_gen)
                     y_p.zero_()
                     y_p[rows, torch.randint(0, self.y_dim, (self.local_batch,), device=self.device, generator=self._eps_gen)] = 1
