@@ -152,7 +152,8 @@ typedef struct cvg_pack_job {
     const float* canonical;
     void* packed;
     int64_t n_groups;            /* 8-element groups of the packed buffer               */
-    int32_t block0, mode;        /* mode 0: row-major [rows][ld], 1: fragment order     */
+    int32_t block0, mode;        /* mode 0: row-major [rows][ld], 1: fragment order, 2: row-major
+                                    with a tiled thread order for transposed layouts      */
     int32_t rows, ld, nchunks, ntaps, Cin, dtype;
 } cvg_pack_job;
 int cvg_weight_pack_job(const cvg_conv_desc* d, const cvg_wmap* map, const float* canonical,
