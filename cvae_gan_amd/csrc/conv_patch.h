@@ -12,6 +12,9 @@ struct PatchPlan {
     int KH, KW, T;
     int tiles_y, tiles_x, groups;
     int patch_px, nchunks;
+    int gstride;                 // grid depth: a workgroup takes image groups z, z + gstride, ... (== groups: one each)
+    int stage_off;               // LDS offset of the output staging area (0: over the patch buffers)
+    int walk;                    // 1: the kernel form whose workgroups go on to further image groups
     size_t lds_bytes;
 };
 

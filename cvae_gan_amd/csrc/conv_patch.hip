@@ -12,6 +12,7 @@
 //                both operands are read from LDS with transposing reads; the dY
 //                fragment is reused across all taps
 #include <stdlib.h>
+#include <stdio.h>
 #include "conv_patch.h"
 #include "gemm_util.h"
 
@@ -37,6 +38,12 @@ struct PatchFwdArgs {
     int nchunks, patch_px, patch_bytes;
     int lane_perm;                          // lane groups of an LDS read take consecutive pixels: lane_pixel()
     int row_fast;                           // tile rows hold a multiple of the epilogue's pixels per thread
+    // A workgroup keeps its tile position and output-channel tile and walks over image groups
+    // blockIdx.z, blockIdx.z + gstride, ... < groups (gstride = gridDim.z).  Every per-thread offset is
+    // the same for each of them, so the next group's first patches and the weight ring are requested
+    // while the current group is still being multiplied.  gstride == groups: one group per workgroup.
+    int groups, gstride;
+    int stage_off;                          // LDS offset of the epilogue's staging area (0: over the patch buffers)
 #ifdef EXP_TIMING
     long long* dbg;
 #endif
@@ -119,7 +126,9 @@ template <> __device__ __forceinline__ void piece_values<bf16>(u32x4 v, float (&
 // ======================================================================================
 // forward
 // ======================================================================================
-template <typename T, int WM, int WN, int MI, int NI, int KWT>
+// WALK: the workgroup goes on to further image groups (see PatchFwdArgs::gstride); the weight ring and
+// the next patches then stay live across the epilogue, which is arranged to need fewer registers.
+template <typename T, int WM, int WN, int MI, int NI, int KWT, bool WALK = false>
 __global__ void __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && NI == 1) ? 2 : 1)     // waves per SIMD
 patch_fwd(const PatchFwdArgs a) {
     constexpr int ES = (int)sizeof(T);
@@ -151,10 +160,13 @@ patch_fwd(const PatchFwdArgs a) {
     // 64-bit base of this workgroup's first image; every offset below is relative to it and fits 32 bits
     // (at most TB images), so a batch may hold more than 2^31 elements
     const T* __restrict__ xp = (const T*)a.x + (size_t)b0 * a.x_img_pitch;
+    const int my_groups = WALK ? (a.groups - (int)blockIdx.z + a.gstride - 1) / a.gstride : 1;     // >= 1
+    const size_t xstep = (size_t)a.gstride * t.TB * a.x_img_pitch;
 #ifdef EXP_TIMING
-    long long tt[5];
+    long long tt[5], tsum[4] = {0, 0, 0, 0};     // phase stamps of the current image group; sums over the groups
     const long long wall0 = wall_clock64();
-    tt[0] = __builtin_readcyclecounter();
+    const long long tstart = __builtin_readcyclecounter();
+    tt[0] = tstart;
 #endif
 
     // ---- weight fragment streams (one per 32-row block of this wave).  The ring of the first TU
@@ -167,7 +179,6 @@ patch_fwd(const PatchFwdArgs a) {
         wptr[ni] = (const T*)a.wf + ((size_t)((n0 + wn * WTN) / 32 + ni) * nsteps * 2) * FRAG + lane * 8;
     frag wr[TU][NI][2];
     auto load_w = [&](int step, frag (&w)[NI][2]) {
-        step = min(step, nsteps - 1);            // the tail re-reads the last step instead of branching
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             w[ni][0] = *(const frag*)(wptr[ni] + (size_t)(step * 2) * FRAG);
@@ -175,7 +186,8 @@ patch_fwd(const PatchFwdArgs a) {
         }
     };
 #pragma unroll
-    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);
+    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);          // nsteps >= TU for every instantiated tap count
+    int wnext = TU < nsteps ? TU : 0;            // next step to request; wraps, so the ring runs on into the next image group
 
     // ---- patch pieces of this thread: global element offset at chunk 0; padding pieces read
     // element 0 and are zeroed by `pmask` afterwards (no branch around the loads)
@@ -200,11 +212,20 @@ patch_fwd(const PatchFwdArgs a) {
         }
     }
     u32x4 pv[NIT];
-    auto load_patch = [&](int chunk) {
+    // Patch requests run two chunks ahead of the multiplications along the sequence (group 0: chunks
+    // 0..nchunks-1, group 1: ...); past the end they repeat the last chunk instead of branching.
+    const T* __restrict__ pf_ptr = xp;
+    int pf_chunk = 0, pf_groups_left = my_groups - 1;
+    auto load_patch = [&]() {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) pv[i] = *(const u32x4*)(xp + (size_t)gofs[i] + chunk * CK);
+        for (int i = 0; i < NIT; ++i) pv[i] = *(const u32x4*)(pf_ptr + (size_t)gofs[i] + pf_chunk * CK);
+        if (pf_chunk + 1 < a.nchunks) {
+            ++pf_chunk;
+        } else if (pf_groups_left > 0) {
+            pf_chunk = 0; pf_ptr += xstep; --pf_groups_left;
+        }
     };
-    load_patch(0);                               // in flight during the rest of the set-up
+    load_patch();                                // in flight during the rest of the set-up
     // Branch-free on purpose: a store inside a conditional block puts the wait for its load inside
     // that block too, and the loop then has to drain every outstanding load (the whole weight ring)
     // before the next patch load may reuse the registers.  Pieces beyond the patch go to the 16
@@ -237,17 +258,9 @@ patch_fwd(const PatchFwdArgs a) {
     }
 
     f32x16 acc[NI][MI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 #ifdef EXP_TIMING
     long long tp[3];
     tp[0] = __builtin_readcyclecounter();
-#endif
-#ifdef EXP_TIMING
     tp[1] = __builtin_readcyclecounter();
 #endif
     store_patch(smem);
@@ -258,15 +271,40 @@ patch_fwd(const PatchFwdArgs a) {
 #ifdef EXP_TIMING
     tt[1] = __builtin_readcyclecounter();
 #endif
-    load_patch(min(1, a.nchunks - 1));
+    load_patch();
 
     // groups of TU taps per chunk: a compile-time count, so the compiler knows how many weight loads
     // are younger than the patch loads when store_patch waits for them (with a run-time count it has
     // to assume none and drains the whole ring at every chunk boundary)
     constexpr int NGRP = (KWT == 1 ? 7 : KWT * KWT) / TU;
-    int step = 0;
+    int bsel = 0;                                // patch buffer of the chunk being multiplied
+    // A walking workgroup keeps its output channels: their bias values are fetched once, here, and the
+    // epilogue has no load of its own in front of the staging (a load there is the youngest one in flight,
+    // so waiting for it would also wait for the patches and weights requested for the next image group).
+    float bpre[NI][4][4];
+    if (WALK) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wn * WTN + ni * 32 + 8 * g4 + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bpre[ni][g4][j] = (a.bias && n < a.N) ? a.bias[n + j] : 0.f;
+            }
+    }
+    for (int gi = 0; gi < my_groups; ++gi) {
+    const int bcur = b0 + gi * a.gstride * t.TB;     // first image of this group
+#ifdef EXP_TIMING
+    if (gi > 0) tt[0] = tt[1] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const char* buf = smem + (chunk & 1) * a.patch_bytes;
+        const char* buf = smem + bsel * a.patch_bytes;
 #pragma unroll 1
         for (int grp = 0; grp < NGRP; ++grp) {
             // PIPE (one wave per SIMD, registers to spare): the LDS reads of step j+1 are issued
@@ -299,25 +337,27 @@ patch_fwd(const PatchFwdArgs a) {
                     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[j][ni][sub], xf[j & 1][sub][mi]);
-                load_w(step + TU, wr[j]);
-                ++step;
+                load_w(wnext, wr[j]);
+                wnext = wnext + 1 < nsteps ? wnext + 1 : 0;
                 // keep each step's LDS reads and MFMAs together: without this the scheduler hoists
                 // the reads of all TU steps to the top of the body and runs out of registers
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // chunk boundary: publish the next patch (a repeat of the last one at the very end), fetch
-        // the one after it
-        store_patch(smem + ((chunk + 1) & 1) * a.patch_bytes);
+        // chunk boundary: publish the next patch (the next group's first one after the last chunk; a
+        // repeat of the last one at the very end), fetch the one after it
+        bsel ^= 1;
+        store_patch(smem + bsel * a.patch_bytes);
         __syncthreads();
-        load_patch(min(chunk + 2, a.nchunks - 1));
+        load_patch();
     }
 
     // ---- epilogue.  D[row = n][col = pixel]: a lane holds 4 consecutive channels of one pixel, so
     // direct stores would scatter 8-byte pieces over 32 cache lines per instruction.  The tile goes
-    // through LDS instead (the patch buffers are free: every wave passed the barrier that follows
-    // its last read) and leaves as whole pixel rows, 16 bytes per lane, consecutive lanes on
-    // consecutive addresses.
+    // through LDS instead and leaves as whole pixel rows, 16 bytes per lane, consecutive lanes on
+    // consecutive addresses.  With one image group per workgroup the staging area lies over the patch
+    // buffers (free: every wave passed the barrier that follows its last read); a workgroup that goes on
+    // to another group has the next patch in one of them already and stages behind them (stage_off).
 #ifdef EXP_TIMING
     tt[2] = __builtin_readcyclecounter();
 #endif
@@ -326,20 +366,35 @@ patch_fwd(const PatchFwdArgs a) {
     // tile pixels).  It is set up here, before the staging, so that a residual term (res *
     // LeakyReLU'(gate): the skip branch of a res block's input gradient) can be requested now, as whole
     // 16-byte pieces on consecutive lanes, and arrive while the accumulators go through LDS.
-    const size_t ybase = (size_t)b0 * a.y_img_pitch;      // res and gate are laid out as y
+    // The walking form recomputes the epilogue's thread mapping from an opaque copy of the thread index in
+    // every round: hoisted out of the loop over image groups, its values would occupy registers during the
+    // multiplications, where none are free.
+    // (the lane index comes back from the execution mask and the wave index is wave-uniform, so not even the
+    // thread index has to survive the multiplications in a vector register)
+    int etid = tid;
+    if (WALK) {
+        int zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        etid = __builtin_amdgcn_readfirstlane(tid >> 6) * 64 +
+               (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
+    }
+    const int elane = etid & 63, ewave = etid >> 6, ewm = ewave / WN, ewn = ewave % WN, eh = elane >> 5;
+    const int elpx = lane_pixel(elane & 31, a.lane_perm);
+    char* const stg = smem + (WALK ? a.stage_off : 0);
+    const size_t ybase = (size_t)bcur * a.y_img_pitch;    // res and gate are laid out as y
     T* __restrict__ yp = (T*)a.y + ybase;
     constexpr int PPR = BN * ES / 16;            // 16-byte pieces per staged row
     constexpr int BMT = WM * WTM;
     constexpr int EPP = 16 / ES;                 // elements per piece
     constexpr int PT = BMT * PPR / NT;           // pixels per thread
-    const int pc = tid % PPR, q0 = (tid / PPR) * PT;
+    const int pc = etid % PPR, q0 = (etid / PPR) * PT;
     const int n_out = n0 + pc * EPP;
     const bool whole = n_out + EPP <= a.N;       // else N is a multiple of 4: half a 16-bit piece
     int yo[PT];                                  // element offset of pixel q0 + i in y, -1: not stored
     if (a.row_fast) {                            // the PT pixels share one output row
         int tb, ty, tx;
         tile_px(t, q0 < t.npx ? q0 : 0, tb, ty, tx);
-        const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+        const int b = bcur + tb, oy = y0 + ty, ox = x0 + tx;
         const bool ok = n_out < a.N && q0 < t.npx && b < a.B && oy < a.OH;
         const int step = a.ox_mul * a.y_pix_pitch;
         int yoff = tb * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch;
@@ -354,14 +409,14 @@ patch_fwd(const PatchFwdArgs a) {
             const int q = q0 + i;
             int tb, ty, tx;
             tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
-            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            const int b = bcur + tb, oy = y0 + ty, ox = x0 + tx;
             const bool ok = n_out < a.N && q < t.npx && b < a.B && oy < a.OH && ox < a.OW;
             yo[i] = ok ? tb * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
         }
     }
     const bool res_mode = a.res != nullptr;      // with a.scale: y = act(scale * conv + shift + res)
     u32x4 rr[PT], gg[PT];
-    if (res_mode) {
+    auto fetch_res = [&]() __attribute__((always_inline)) {
         const T* __restrict__ resp = (const T*)a.res + ybase;
         auto fetch = [&](const T* __restrict__ src, u32x4 (&dst)[PT]) __attribute__((always_inline)) {
 #pragma unroll
@@ -377,28 +432,32 @@ patch_fwd(const PatchFwdArgs a) {
         };
         fetch(resp, rr);
         if (a.gate) fetch((const T*)a.gate + ybase, gg);
-    }
+    };
+    if (res_mode && !WALK) fetch_res();          // WALK: after the staging, when the accumulators are dead
     const bool per_pixel = a.cbias != nullptr;   // the class bias needs the pixel's image
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int ql = wm * WTM + mi * 32 + lpx;
+        const int ql = ewm * WTM + mi * 32 + elpx;
         const float* cb = nullptr;
         if (per_pixel) {
             int tb, ty, tx;
             tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
-            const int b = b0 + tb;
+            const int b = bcur + tb;
             if (ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int nl = wn * WTN + ni * 32 + 8 * g4 + 4 * h, n = n0 + nl;
+                const int nl = ewn * WTN + ni * 32 + 8 * g4 + 4 * eh, n = n0 + nl;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g4 + j];
                 if (n < a.N) {
-                    if (a.bias) {
+                    if (WALK) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += bpre[ni][g4][j];
+                    } else if (a.bias) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += a.bias[n + j];
                     }
@@ -415,21 +474,31 @@ patch_fwd(const PatchFwdArgs a) {
                         }
                     }
                 }
-                store4<T>((T*)(smem + ql * OP) + nl, v);
+                store4<T>((T*)(stg + ql * OP) + nl, v);
             }
         }
     }
     __syncthreads();
+    if (WALK) {
+        // defined on every path: a value set under a condition only would count as carried from one image
+        // group to the next and hold its registers through the multiplications
+#pragma unroll
+        for (int i = 0; i < PT; ++i) rr[i] = gg[i] = u32x4{0u, 0u, 0u, 0u};
+        if (res_mode) fetch_res();
+    }
 #ifdef EXP_TIMING
     tt[3] = __builtin_readcyclecounter();
     auto finish = [&]() {
-        __builtin_amdgcn_s_waitcnt(0);
+        if (!WALK || gi == my_groups - 1) __builtin_amdgcn_s_waitcnt(0);     // (a walking workgroup keeps its requests in flight)
         tt[4] = __builtin_readcyclecounter();
-        if (tid == 0) {
+        for (int k = 0; k < 4; ++k) tsum[k] += tt[k + 1] - tt[k];
+        if (etid == 0 && gi == my_groups - 1) {
             const size_t lin = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
             if (lin < 65536) {
-                for (int k = 0; k < 5; ++k) a.dbg[lin * 5 + k] = tt[k];
-                for (int k = 0; k < 2; ++k) a.dbg[65536 * 5 + lin * 3 + k] = tp[k] - tt[0];
+                long long c = tstart;
+                a.dbg[lin * 5] = c;
+                for (int k = 0; k < 4; ++k) { c += tsum[k]; a.dbg[lin * 5 + k + 1] = c; }
+                for (int k = 0; k < 2; ++k) a.dbg[65536 * 5 + lin * 3 + k] = tp[k] - tstart;
                 a.dbg[65536 * 5 + lin * 3 + 2] = wall_clock64() - wall0;
             }
         }
@@ -445,7 +514,7 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         if (yo[i] < 0) continue;
-        u32x4 v = *(const u32x4*)(smem + (q0 + i) * OP + pc * 16);
+        u32x4 v = *(const u32x4*)(stg + (q0 + i) * OP + pc * 16);
         if (res_mode) v = add_gated<T>(v, rr[i], gg[i], gated, a.scale && a.act);
         if (want_stats) {                             // of the values as stored (rounded to T), in pixel order
             float f[EPP];
@@ -460,7 +529,7 @@ patch_fwd(const PatchFwdArgs a) {
         // Threads with equal pc hold sums of the same EPP channels: inside a wave they sit PPR lanes apart
         // (butterfly, both partners compute the same sum), the waves meet in LDS and are added in wave
         // order, so a tile's partial does not depend on scheduling.  One partial row per pixel tile:
-        // ws[which][tile][channel], tile = blockIdx.x + gridDim.x * blockIdx.z.
+        // ws[which][tile][channel], tile = blockIdx.x + gridDim.x * image group.
         __shared__ float stat_sm[2][NT / 64][BN];
 #pragma unroll
         for (int o = PPR; o < 64; o <<= 1)
@@ -469,26 +538,27 @@ patch_fwd(const PatchFwdArgs a) {
                 st_s[j] += __shfl_xor(st_s[j], o, 64);
                 st_q[j] += __shfl_xor(st_q[j], o, 64);
             }
-        if (lane < PPR) {
+        if (elane < PPR) {
 #pragma unroll
             for (int j = 0; j < EPP; ++j) {
-                stat_sm[0][wave][lane * EPP + j] = st_s[j];
-                stat_sm[1][wave][lane * EPP + j] = st_q[j];
+                stat_sm[0][ewave][elane * EPP + j] = st_s[j];
+                stat_sm[1][ewave][elane * EPP + j] = st_q[j];
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < a.N) {
+        if (etid < BN && n0 + etid < a.N) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) { s0 += stat_sm[0][w][tid]; s1 += stat_sm[1][w][tid]; }
-            const size_t nblk = (size_t)gridDim.x * gridDim.z, tile = blockIdx.x + (size_t)gridDim.x * blockIdx.z;
-            a.stat_ws[tile * a.N + n0 + tid] = s0;
-            a.stat_ws[(nblk + tile) * a.N + n0 + tid] = s1;
+            for (int w = 0; w < NT / 64; ++w) { s0 += stat_sm[0][w][etid]; s1 += stat_sm[1][w][etid]; }
+            const size_t nblk = (size_t)gridDim.x * a.groups, tile = blockIdx.x + (size_t)gridDim.x * (blockIdx.z + gi * a.gstride);
+            a.stat_ws[tile * a.N + n0 + etid] = s0;
+            a.stat_ws[(nblk + tile) * a.N + n0 + etid] = s1;
         }
     }
 #ifdef EXP_TIMING
     finish();
 #endif
+    }   // image groups
 }
 
 // weights -> fragment order: element ((nblk * nk2*2 + kstep) * 64 + lane) * 8 + j holds
@@ -1023,7 +1093,10 @@ static bool offsets_fit(const cvg_conv_desc* d, int TB) {
 }
 
 // Smallest number of tiles, then the smallest patch, over all TH x TW <= BM.
-bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int& TB, int& TH, int& TW, int S = 1) {
+// whole_groups: a tile whose image count does not divide the batch counts as 4 % more tiles (only whole
+// groups let a workgroup walk over several of them).
+bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int& TB, int& TH, int& TW, int S = 1,
+                 bool whole_groups = false) {
     long best_tiles = -1, best_patch = 0;
     for (int th = 1; th <= OH && th <= BM; ++th)
         for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
@@ -1032,8 +1105,9 @@ bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px
             if (tb > B) tb = B;
             if (tb > max_patch_px / pp) tb = max_patch_px / pp;
             if (tb < 1) continue;
-            const long tiles = (long)ceil_div(OH, th) * ceil_div(OW, tw) * ceil_div(B, tb);
+            long tiles = (long)ceil_div(OH, th) * ceil_div(OW, tw) * ceil_div(B, tb);
             const long patch = tiles * tb * pp;
+            if (whole_groups && B % tb != 0) tiles += tiles / 25;
             if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
                 best_tiles = tiles; best_patch = patch; TB = tb; TH = th; TW = tw;
             }
@@ -1060,8 +1134,17 @@ int set_lds(K kernel, size_t bytes) {
 
 template <typename T, int WM, int WN, int MI, int NI, int KWT>
 int launch_patch_fwd2(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
+    dim3 grid(p.tiles_y * p.tiles_x, ceil_div(a.N, WN * NI * 32), p.gstride);
+    if constexpr (sizeof(T) == 2 && WM == 2 && WN == 4 && NI == 1 && KWT == 3) {
+        if (p.walk) {                            // a workgroup walks over several image groups
+            if (set_lds(patch_fwd<T, WM, WN, MI, NI, KWT, true>, p.lds_bytes)) return -1;
+            patch_fwd<T, WM, WN, MI, NI, KWT, true><<<grid, 64 * WM * WN, p.lds_bytes, s>>>(a);
+            CVG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (p.walk) CVG_FAIL("patch_fwd: no walking form of this kernel");
     if (set_lds(patch_fwd<T, WM, WN, MI, NI, KWT>, p.lds_bytes)) return -1;
-    dim3 grid(p.tiles_y * p.tiles_x, ceil_div(a.N, WN * NI * 32), p.groups);
     patch_fwd<T, WM, WN, MI, NI, KWT><<<grid, 64 * WM * WN, p.lds_bytes, s>>>(a);
     CVG_LAUNCH_CHECK();
     return 0;
@@ -1146,7 +1229,20 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // CVG_PATCH_WIDE: '0' never, '1' the four-wave form with 64 ch x 128 px wave tiles.
     const char mode = wide ? wide[0] : 'a';
     if (d->dtype == CVG_BF16 && d->N > 64 && mode != '0') p.BM = 256;
-    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW)) return;
+    // CVG_PATCH_PERSIST=1: eight-wave workgroups walk over image groups (below).  Off by default: layer by
+    // layer it is 4..8 % faster where a workgroup has several short tiles (K <= 1152), inside the step (weight
+    // gradients running beside it on other streams) it measured 0.3..0.8 % slower.  Read at every call, so
+    // a test can switch it.
+    const char* persist = getenv("CVG_PATCH_PERSIST");
+    const bool may_walk = persist && (persist[0] == '1' || persist[0] == '2') && d->dtype == CVG_BF16 && p.BN == 128 &&
+                          p.BM == 256 && mode != '1' && p.KW == 3;
+    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW, 1, may_walk)) return;
+    {   // CVG_PATCH_TILE=th,tw,tb: tile override (benchmarking)
+        static const char* force = getenv("CVG_PATCH_TILE");
+        int th, tw, tb;
+        if (force && sscanf(force, "%d,%d,%d", &th, &tw, &tb) == 3 && th * tw * tb <= p.BM &&
+            tb * (th + p.KH - 1) * (tw + p.KW - 1) <= max_patch) { p.TH = th; p.TW = tw; p.TB = tb; }
+    }
     if (!offsets_fit(d, p.TB)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
     p.tiles_y = ceil_div(d->OH, p.TH); p.tiles_x = ceil_div(d->OW, p.TW); p.groups = ceil_div(d->B, p.TB);
@@ -1161,6 +1257,25 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     if (p.lds_bytes < stage_bytes) p.lds_bytes = stage_bytes;
     static const char* extra = getenv("CVG_PATCH_LDS_EXTRA");      // occupancy experiments
     if (extra) p.lds_bytes += (size_t)atoi(extra);
+    // One image group per workgroup unless the layer qualifies for the walking form: eight-wave
+    // workgroups (one per CU), whole groups only, at most one workgroup per CU in the grid and at least
+    // two groups for each.  The workgroup then pays its set-up (address arithmetic, first patch, weight
+    // ring: about 5k cycles against 28k of multiplications per 256 x 128 tile at K = 1152) once instead
+    // of once per tile.
+    p.gstride = p.groups; p.stage_off = 0; p.walk = 0;
+    const int slots = 256;                                            // workgroups resident at once: one per CU
+    const int fixed = p.tiles_y * p.tiles_x * ceil_div(d->N, p.BN);   // workgroups per image group
+    if (may_walk && d->B % p.TB == 0 && fixed <= slots && p.groups >= 2) {
+        int stride = slots / fixed;
+        if (stride > p.groups) stride = p.groups;
+        const int walks = ceil_div(p.groups, stride);
+        stride = ceil_div(p.groups, walks);                           // same number of rounds, evenly filled
+        const size_t need = 2 * (size_t)patch_bytes + stage_bytes;
+        if (walks >= 2 && need + 8 * 1024 <= 160 * 1024) {            // + the statistics scratch of the kernel
+            p.gstride = stride; p.stage_off = 2 * patch_bytes; p.lds_bytes = need; p.walk = 1;
+            if (persist && persist[0] == '2') p.gstride = p.groups;   // the walking kernel, one group each (benchmarking)
+        }
+    }
     p.ok = 1;
 }
 
@@ -1180,6 +1295,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
     a.nchunks = p.nchunks; a.patch_px = p.patch_px;
     a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
+    a.groups = p.groups; a.gstride = p.gstride; a.stage_off = p.stage_off;
     // Each ds_read_b128 lane group then reads 16 CONSECUTIVE tile pixels.  With 16-pixel tile rows that is
     // one row (conflict-free); with other widths the 16 pixels cross a row boundary and two of them collide
     // (2 LDS cycles instead of 1), where the natural lane order spreads a group over 28 consecutive pixels
@@ -1199,7 +1315,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
         static long long* dbg = nullptr;
         if (!dbg) { if (hipMalloc(&dbg, 65536 * 8 * 8) != hipSuccess) return -1; }
         a.dbg = dbg;
-        g_dbg = dbg; g_dbg_blocks = (long long)p.tiles_y * p.tiles_x * ceil_div(d->N, p.BN) * p.groups;
+        g_dbg = dbg; g_dbg_blocks = (long long)p.tiles_y * p.tiles_x * ceil_div(d->N, p.BN) * p.gstride;
     }
 #endif
     fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);

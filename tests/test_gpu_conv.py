@@ -119,6 +119,38 @@ def test_conv_bias_residual_gate(dtype):
     assert relmax(from_rows(yr, B, H, H, cout), ref) < TOL[dtype]
 
 
+def test_walking_workgroups_bit_identical(monkeypatch):
+    """CVG_PATCH_PERSIST=1: eight-wave workgroups of patch_fwd keep their tile position and walk over several
+    image groups (bias preloaded, residual fetched after the staging, output staged behind the patch buffers).
+    Same products in the same order: the output must equal the default form's bit for bit, with bias,
+    residual and gate, and with a group count that the walks do not divide (130 images over 44 phases)."""
+    ops, _desc, _wmap = _mods()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    B, H, cin, cout = 130, 32, 64, 128
+    x = torch.randn(B, cin, H, H, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / 24).bfloat16().float()
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g).bfloat16().float()
+    gate = torch.randn(B, cout, H, H, generator=g).bfloat16().float()
+    ref = F.conv2d(x, w, bias, 1, 1) + res * torch.where(gate > 0, 1.0, 0.2)
+    d = _desc(dtype, B, H, H, cin, H, H, cout, 3, 9, off=(-1, -1))
+    wm = _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9)
+    xr, rr, gr, pk = to_rows(x, dtype), to_rows(res, dtype), to_rows(gate, dtype), pack(ops, wm, w, d, dtype)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CVG_PATCH_PERSIST", mode)
+        for with_res in (False, True):
+            yr = torch.zeros(B * H * H, cout, dtype=dtype, device="cuda")
+            ops.conv_fwd(d, xr, pk, yr, bias=bias.cuda(), res=rr if with_res else None, gate=gr if with_res else None,
+                         ws=ws_for(ops, d))
+            torch.cuda.synchronize()
+            out[mode, with_res] = yr
+    assert relmax(from_rows(out["1", True], B, H, H, cout), ref) < TOL[dtype]
+    assert torch.equal(out["0", True], out["1", True])
+    assert torch.equal(out["0", False], out["1", False])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_output_gate(dtype):
     """gate without res: the output is multiplied by the LeakyReLU derivative of `gate` (gather
