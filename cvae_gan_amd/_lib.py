@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("CVG_LIB") or os.path.join(_HERE, "lib", "libcvaegan_h
 
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
+FORM_GATHER, FORM_S2_TRANSPOSED = 0, 1
+CONV_ALONE = 1
 
 
 class ConvDesc(C.Structure):
@@ -23,7 +25,7 @@ class ConvDesc(C.Structure):
         "dtype", "B", "H", "W", "Cin", "x_img_pitch", "x_row_pitch", "x_pix_pitch",
         "OH", "OW", "N", "KW", "ntaps", "stride", "tstep_y", "tstep_x", "off_y", "off_x",
         "pad_mode", "y_img_pitch", "y_row_pitch", "y_pix_pitch", "oy_mul", "oy_off",
-        "ox_mul", "ox_off", "w_ld", "w_rows", "co_launches")]
+        "ox_mul", "ox_off", "w_ld", "w_rows", "co_launches", "form", "flags")]
 
 
 class WMap(C.Structure):

@@ -1,6 +1,7 @@
 // Library-level entry points: version and last-error text.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -11,7 +12,34 @@ void cvg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Benchmarking (A/B) switches: the environment is read once, here, when the first kernel is planned.
+const CvgSwitches& cvg_switches() {
+    static const CvgSwitches sw = [] {
+        CvgSwitches w;
+        memset(&w, 0, sizeof(w));
+        auto on = [](const char* name) { return getenv(name) != nullptr; };
+        auto ch = [](const char* name) { const char* e = getenv(name); return e ? e[0] : '\0'; };
+        auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+        w.no_patch = on("CVG_NO_PATCH");
+        w.no_xcd_remap = on("CVG_NO_XCD_REMAP");
+        w.patch_2w = on("CVG_PATCH_2W");
+        w.wgrad_s2_gather = on("CVG_WGRAD_S2_GATHER");
+        w.wgrad_v1 = on("CVG_WGRAD_V1");
+        w.wgrad_4w = on("CVG_WGRAD_4W");
+        w.bn_raw_sums = on("CVG_BN_RAW_SUMS");
+        w.patch_wide = ch("CVG_PATCH_WIDE");
+        w.patch_persist = ch("CVG_PATCH_PERSIST");
+        w.patch_perm = ch("CVG_PATCH_PERM");
+        w.lds_extra = num("CVG_PATCH_LDS_EXTRA");
+        w.wgrad_wgs = num("CVG_WGRAD_WGS");
+        const char* tile = getenv("CVG_PATCH_TILE");
+        w.tile_set = tile && sscanf(tile, "%d,%d,%d", &w.tile[0], &w.tile[1], &w.tile[2]) == 3;
+        return w;
+    }();
+    return sw;
+}
+
 extern "C" {
-int cvg_version(void) { return 1; }
+int cvg_version(void) { return 2; }
 const char* cvg_last_error(void) { return g_err; }
 }

@@ -25,6 +25,25 @@ void cvg_set_error(const char* fmt, ...);
 #define CVG_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) CVG_FAIL("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
 
+// ---- benchmarking switches (environment variables, read once per process; none changes results) ----
+struct CvgSwitches {
+    bool no_patch;            // CVG_NO_PATCH: every convolution on the gather kernels
+    bool no_xcd_remap;        // CVG_NO_XCD_REMAP: weight-gradient workgroups in launch order
+    bool patch_2w;            // CVG_PATCH_2W: two-wave workgroups for 64-channel patch_fwd layers
+    bool wgrad_s2_gather;     // CVG_WGRAD_S2_GATHER: stride-2 weight gradients on the gather kernel
+    bool wgrad_v1;            // CVG_WGRAD_V1: tap-split weight-gradient kernel instead of the nine-tap one
+    bool wgrad_4w;            // CVG_WGRAD_4W: four-wave nine-tap weight-gradient workgroups
+    bool bn_raw_sums;         // CVG_BN_RAW_SUMS: BatchNorm sums about 0 instead of about row 0
+    char patch_wide;          // CVG_PATCH_WIDE: '0' no eight-wave tiles, '1' 64-channel wave tiles
+    char patch_persist;       // CVG_PATCH_PERSIST: '0' no walking workgroups, '1' on every eligible layer, '2' the
+                              // walking kernel with one image group per workgroup; unset: the descriptor's flag
+    char patch_perm;          // CVG_PATCH_PERM: '0' natural lane order of the LDS reads
+    int lds_extra;            // CVG_PATCH_LDS_EXTRA: bytes of LDS added per workgroup (occupancy experiments)
+    int wgrad_wgs;            // CVG_WGRAD_WGS: workgroups a weight-gradient launch aims for
+    bool tile_set; int tile[3];   // CVG_PATCH_TILE=th,tw,tb
+};
+const CvgSwitches& cvg_switches();
+
 // ---- exact division by a runtime constant ---------------------------------------
 // q = floor(m / d) for 0 <= m < 2^31 with one v_mul_hi_u32 and a shift.
 // mul = ceil(2^(31+l) / d), l = ceil(log2 d); d == 1 is encoded as mul == 0.

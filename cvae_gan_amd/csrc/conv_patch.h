@@ -47,3 +47,16 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p);
 int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const void* x, const void* dy, int dy_ld,
                        int dy_img_pitch, int dy_row_pitch, int dy_cols,
                        const cvg_wmap* map, float* grad, int accumulate, float* ws, hipStream_t s);
+
+// Input gradient of a 3x3 stride-2 zero-padded convolution, all four output-parity classes in one launch
+// (descriptors with form == CVG_FORM_S2_TRANSPOSED).  Weights in fragment order [n/32][chunk][tap 0..8][k16 half]
+// [lane][8] with n the result's channel and k the dY channel.
+struct S2tPlan {
+    int ok;
+    int BN;                      // result channels per workgroup (128 positions of the dY grid each)
+    int TB, TH, TW, tiles_y, tiles_x, groups, patch_px, nchunks;
+    size_t lds_bytes;
+};
+void patch_dgrad_s2_plan(const cvg_conv_desc* d, S2tPlan& p);
+int patch_dgrad_s2_launch(const cvg_conv_desc* d, const S2tPlan& p, const void* dy, const void* w, void* dx,
+                          const void* gate, hipStream_t s);

@@ -13,6 +13,7 @@
 //                fragment is reused across all taps
 #include <stdlib.h>
 #include <stdio.h>
+#include <mutex>
 #include "conv_patch.h"
 #include "gemm_util.h"
 
@@ -1067,6 +1068,217 @@ __global__ void __launch_bounds__(64 * WN * WC, 1) patch_wgrad9(const PatchWgrad
     }
 }
 
+
+// ======================================================================================
+// input gradient of a 3x3, stride-2, zero-padding-1 convolution: all four output-parity classes in one pass
+// ======================================================================================
+// dX[2a + py][2b + px] = sum over the taps (kh, kw) with (kh != 1, kw != 1) == (py, px) of
+// dY[a + (kh == 0)][b + (kw == 0)] . W[.][.][kh][kw]: class (0, 0) has one tap, (0, 1) and (1, 0) two, (1, 1) four.
+// A workgroup owns TB x TH x TW positions (a, b) of the dY grid and stages their (TH + 1) x (TW + 1) patch once per
+// 32-channel chunk; the nine taps then read shifted fragments from it, each into the accumulators of its own
+// class, so every staged byte and every weight fragment is used exactly once and no MFMA multiplies a structural
+// zero (run as four separate convolutions, dY leaves L2 once per class and the one-tap class is a 1 x 1
+// convolution that re-stages its input for every 32 x 32 block of work).  Wave tile: 32 channels x 64 positions
+// x 4 classes (eight accumulator blocks); the four classes of a position are the 2 x 2 output pixels it owns.
+struct S2tArgs {
+    const void* x; const void* wf; void* y; const void* gate;
+    int B, H, W;                                   // dY grid
+    int x_img_pitch, x_row_pitch, x_pix_pitch;
+    int N;                                         // channels of the result
+    int y_img_pitch, y_row_pitch, y_pix_pitch;     // result [B][2H][2W][N]; gate is laid out the same
+    int nchunks, patch_px, patch_bytes, lane_perm, row_fast;
+    TileGeom t;
+};
+
+template <typename T, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN, sizeof(T) == 2 ? 2 : 1)
+patch_dgrad_s2(const S2tArgs a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CPP = CK * ES / 16, PITCH = CK * ES + 16;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int MI = 2, WTM = MI * 32, BMQ = WM * WTM, BN = WN * 32;
+    constexpr int MAXPATCH = 256;                                    // patch pixels a workgroup can stage
+    constexpr int NIT = (MAXPATCH * CPP + NT - 1) / NT;
+    constexpr int FRAG = 64 * 8;
+    constexpr int TU = ES == 2 ? 9 : 3, NGRP = 9 / TU;               // weight steps in flight (see patch_fwd)
+    typedef typename Elem<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const TileGeom& t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tile_y = fdiv(blockIdx.x, t.div_tx), tile_x = blockIdx.x - tile_y * t.tiles_x;
+    const int y0 = tile_y * t.TH, x0 = tile_x * t.TW, b0 = blockIdx.z * t.TB, n0 = blockIdx.y * BN;
+    const T* __restrict__ xp = (const T*)a.x + (size_t)b0 * a.x_img_pitch;
+
+    const int nsteps = a.nchunks * 9;
+    const T* wptr = (const T*)a.wf + ((size_t)((n0 + wn * 32) / 32) * nsteps * 2) * FRAG + lane * 8;
+    frag wr[TU][2];
+    auto load_w = [&](int step, frag (&w)[2]) {
+        w[0] = *(const frag*)(wptr + (size_t)(step * 2) * FRAG);
+        w[1] = *(const frag*)(wptr + (size_t)(step * 2 + 1) * FRAG);
+    };
+#pragma unroll
+    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);
+    int wnext = TU < nsteps ? TU : 0;
+
+    int gofs[NIT], sofs[NIT];
+    unsigned pmask = 0;
+    const int nitems = a.patch_px * CPP;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + NT * i;
+        gofs[i] = 0;
+        sofs[i] = CK * ES;                       // pieces beyond the patch: the padding bytes of patch pixel 0
+        if (idx < nitems) {
+            const int p = idx / CPP, ci = idx % CPP;
+            sofs[i] = p * PITCH + ci * 16;
+            const int tb = fdiv(p, t.div_phw);
+            const int r = p - tb * (t.PH * t.PW);
+            const int py = fdiv(r, t.div_pw), px = r - py * t.PW;
+            const int iy = y0 + py, ix = x0 + px, b = b0 + tb;
+            if (b < a.B && iy < a.H && ix < a.W) {
+                gofs[i] = tb * a.x_img_pitch + iy * a.x_row_pitch + ix * a.x_pix_pitch + ci * (16 / ES);
+                pmask |= 1u << i;
+            }
+        }
+    }
+    u32x4 pv[NIT];
+    int pf_chunk = 0;
+    auto load_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) pv[i] = *(const u32x4*)(xp + (size_t)gofs[i] + pf_chunk * CK);
+        if (pf_chunk + 1 < a.nchunks) ++pf_chunk;                    // past the end: the last chunk again
+    };
+    auto store_patch = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            u32x4 v = pv[i];
+            if (!((pmask >> i) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+            *(u32x4*)(buf + sofs[i]) = v;
+        }
+    };
+    load_patch();
+
+    int abase[MI];
+    const int lpx = lane_pixel(l31, a.lane_perm);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        int q = wm * WTM + mi * 32 + lpx;
+        if (q >= t.npx) q = 0;
+        int tb, ty, tx;
+        tile_px(t, q, tb, ty, tx);
+        abase[mi] = ((tb * t.PH + ty) * t.PW + tx) * PITCH + 8 * h * ES;
+    }
+
+    f32x16 acc[4][MI];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][mi][r] = 0.f;
+
+    store_patch(smem);
+    __syncthreads();
+    load_patch();
+    int bsel = 0;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const char* buf = smem + bsel * a.patch_bytes;
+#pragma unroll
+        for (int grp = 0; grp < NGRP; ++grp) {
+#pragma unroll
+            for (int j = 0; j < TU; ++j) {
+                const int tap = grp * TU + j, kh = tap / 3, kw = tap % 3;          // constants after unrolling
+                const int cls = (kh != 1 ? 2 : 0) + (kw != 1 ? 1 : 0);
+                const int tapoff = ((kh == 0 ? t.PW : 0) + (kw == 0 ? 1 : 0)) * PITCH;
+                frag xf[2][MI];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        xf[sub][mi] = *(const frag*)(buf + abase[mi] + tapoff + sub * 16 * ES);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) mma32(acc[cls][mi], wr[j][sub], xf[sub][mi]);
+                load_w(wnext, wr[j]);
+                wnext = wnext + 1 < nsteps ? wnext + 1 : 0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        bsel ^= 1;
+        store_patch(smem + bsel * a.patch_bytes);
+        __syncthreads();
+        load_patch();
+    }
+
+    // ---- epilogue: one output row parity at a time (two classes = the even and odd columns of those rows)
+    // through LDS, staged row 2 q + px for position q, so that consecutive staged rows are consecutive output
+    // pixels; whole pixel rows then leave 16 bytes per lane.  The gate pieces (LeakyReLU'(r) of the activation
+    // in front of the convolution) are requested before the staging and multiplied on the way out.
+    constexpr int OP = BN * ES + 16, PPR = BN * ES / 16, EPP = 16 / ES;
+    constexpr int BMT = 2 * BMQ, PT = BMT * PPR / NT;
+    static_assert(PT % 2 == 0, "a thread's staged rows start at an even row");
+    const int pc = tid % PPR, r0 = (tid / PPR) * PT;
+    const int n_out = n0 + pc * EPP;
+    const bool col_ok = n_out < a.N;                 // N is a multiple of EPP: pieces are whole
+    T* __restrict__ yp = (T*)a.y + (size_t)b0 * a.y_img_pitch;
+    const T* __restrict__ gp = a.gate ? (const T*)a.gate + (size_t)b0 * a.y_img_pitch : nullptr;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        int yo[PT];
+        if (a.row_fast) {                            // the PT staged rows of a thread lie in one output row
+            const int ql = r0 >> 1;
+            int tb, ty, tx;
+            tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+            const bool ok = col_ok && ql < t.npx && b0 + tb < a.B && y0 + ty < a.H;
+            const int yoff = tb * a.y_img_pitch + (2 * (y0 + ty) + py) * a.y_row_pitch + 2 * (x0 + tx) * a.y_pix_pitch + n_out;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) yo[i] = (ok && x0 + tx + (i >> 1) < a.W) ? yoff + i * a.y_pix_pitch : -1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int r = r0 + i, ql = r >> 1, px = r & 1;
+                int tb, ty, tx;
+                tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+                const bool ok = col_ok && ql < t.npx && b0 + tb < a.B && y0 + ty < a.H && x0 + tx < a.W;
+                yo[i] = ok ? tb * a.y_img_pitch + (2 * (y0 + ty) + py) * a.y_row_pitch + (2 * (x0 + tx) + px) * a.y_pix_pitch + n_out : -1;
+            }
+        }
+        u32x4 gg[PT];
+        if (gp) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i) gg[i] = *(const u32x4*)(gp + (yo[i] >= 0 ? yo[i] : 0));
+        }
+        if (py) __syncthreads();                     // the first half has left the staging area
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ql = wm * WTM + mi * 32 + lpx;
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int nl = wn * 32 + 8 * g4 + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[py * 2 + px][mi][4 * g4 + j];
+                    store4<T>((T*)(smem + (2 * ql + px) * OP) + nl, v);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            if (yo[i] < 0) continue;
+            u32x4 v = *(const u32x4*)(smem + (r0 + i) * OP + pc * 16);
+            if (gp) v = mul_gate<T>(v, gg[i]);
+            *(u32x4*)(yp + yo[i]) = v;
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x, int S = 1) {
     t.TB = TB; t.TH = TH; t.TW = TW; t.PH = (TH - 1) * S + KH; t.PW = (TW - 1) * S + KW;
@@ -1115,22 +1327,31 @@ bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px
     return best_tiles > 0;
 }
 
-// Dynamic LDS beyond 64 KB has to be granted per kernel and per device; the grant is remembered per
-// kernel instantiation and device (a benign race: two threads may both set the same attribute).
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    constexpr int MAX_DEV = 64;
-    static size_t granted[MAX_DEV];
+// Dynamic LDS beyond 64 KB has to be granted per kernel and per device.  The grants are remembered in a
+// small table keyed by (kernel address, device): instantiations of one template share a function-pointer
+// TYPE, so the key must be the address.
+int set_lds_impl(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
+    struct Grant { const void* fn; int dev; size_t bytes; };
+    constexpr int MAX_GRANTS = 512;
+    static Grant table[MAX_GRANTS];
+    static int n_grants = 0;
+    static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) CVG_FAIL("set_lds: no current device");
-    if (bytes > granted[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) CVG_FAIL("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
-        granted[dev] = bytes;
-    }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) CVG_FAIL("set_lds: no current device");
+    std::lock_guard<std::mutex> lock(mu);
+    Grant* g = nullptr;
+    for (int i = 0; i < n_grants; ++i)
+        if (table[i].fn == kernel && table[i].dev == dev) { g = &table[i]; break; }
+    if (g && g->bytes >= bytes) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) CVG_FAIL("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    if (!g && n_grants < MAX_GRANTS) { g = &table[n_grants++]; g->fn = kernel; g->dev = dev; g->bytes = 0; }
+    if (g) g->bytes = bytes;             // a full table only costs the repeated attribute call
     return 0;
 }
+template <typename K>
+int set_lds(K kernel, size_t bytes) { return set_lds_impl((const void*)kernel, bytes); }
 
 template <typename T, int WM, int WN, int MI, int NI, int KWT>
 int launch_patch_fwd2(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
@@ -1161,8 +1382,7 @@ int launch_patch_wgrad(const PatchWgradPlan& p, const PatchWgradArgs& a, hipStre
     if (set_lds(patch_wgrad<T, WN, WT, TPW, NI>, p.lds_bytes)) return -1;
     PatchWgradArgs b = a;
     b.nchunks = p.nchunks; b.nchunks_ntiles = p.nchunks * p.n_tiles;
-    static const bool no_remap = getenv("CVG_NO_XCD_REMAP") != nullptr;   // A/B switch for benchmarking
-    b.xcd_remap = no_remap ? 0 : 1;
+    b.xcd_remap = cvg_switches().no_xcd_remap ? 0 : 1;
     b.div_chunks = make_fastdiv(p.nchunks); b.div_cn = make_fastdiv(b.nchunks_ntiles);
     const int64_t nwg = (int64_t)b.nchunks_ntiles * p.nsplit;
     if (nwg >= (1ll << 31)) CVG_FAIL("patch_wgrad: too many workgroups");
@@ -1217,31 +1437,27 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // 64-channel layers move as many bytes as they multiply: four independent two-wave workgroups per
     // CU (128 px x 64 ch each) overlap one tile's loads and stores with another's MFMAs better than two
     // four-wave ones
-    static const bool two_wave = getenv("CVG_PATCH_2W") != nullptr;
+    const CvgSwitches& sw = cvg_switches();
     int max_patch = 512;
-    if (two_wave && d->dtype == CVG_BF16 && d->N > 32 && d->N <= 64) { p.BM = 128; max_patch = 192; }
-    static const char* wide = getenv("CVG_PATCH_WIDE");            // experiment: 256 px x 128 ch tiles (bf16)
+    if (sw.patch_2w && d->dtype == CVG_BF16 && d->N > 32 && d->N <= 64) { p.BM = 128; max_patch = 192; }
     // Layers with two or more 128-channel output tiles run as ONE eight-wave workgroup per CU over 256
     // pixels (wave tile unchanged: 32 ch x 128 px): each weight fragment is fetched from L2 once per
     // 256 pixels and its second reader hits the L1, and each input patch is re-read by half as many
     // workgroups.  Layer by layer -2..-25 % for N >= 256 and +5 % for N = 128 in isolation, but inside
     // the step (weight-gradient stream running beside it) using it for every N > 64 is fastest.
     // CVG_PATCH_WIDE: '0' never, '1' the four-wave form with 64 ch x 128 px wave tiles.
-    const char mode = wide ? wide[0] : 'a';
+    const char mode = sw.patch_wide ? sw.patch_wide : 'a';
     if (d->dtype == CVG_BF16 && d->N > 64 && mode != '0') p.BM = 256;
-    // CVG_PATCH_PERSIST=1: eight-wave workgroups walk over image groups (below).  Off by default: layer by
-    // layer it is 4..8 % faster where a workgroup has several short tiles (K <= 1152), inside the step (weight
-    // gradients running beside it on other streams) it measured 0.3..0.8 % slower.  Read at every call, so
-    // a test can switch it.
-    const char* persist = getenv("CVG_PATCH_PERSIST");
-    const bool may_walk = persist && (persist[0] == '1' || persist[0] == '2') && d->dtype == CVG_BF16 && p.BN == 128 &&
-                          p.BM == 256 && mode != '1' && p.KW == 3;
+    // Walking workgroups (below) where the caller says the launch has the GPU to itself (CVG_CONV_ALONE): layer
+    // by layer they are 4..8 % faster where a workgroup has several short tiles (K <= 1152); beside
+    // weight-gradient launches on other streams they measured 0.3..0.8 % slower (256 resident workgroups holding
+    // 122 KB of LDS each leave those launches no CU to share).
+    const bool want_walk = sw.patch_persist ? (sw.patch_persist == '1' || sw.patch_persist == '2') : (d->flags & CVG_CONV_ALONE) != 0;
+    const bool may_walk = want_walk && d->dtype == CVG_BF16 && p.BN == 128 && p.BM == 256 && mode != '1' && p.KW == 3;
     if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW, 1, may_walk)) return;
-    {   // CVG_PATCH_TILE=th,tw,tb: tile override (benchmarking)
-        static const char* force = getenv("CVG_PATCH_TILE");
-        int th, tw, tb;
-        if (force && sscanf(force, "%d,%d,%d", &th, &tw, &tb) == 3 && th * tw * tb <= p.BM &&
-            tb * (th + p.KH - 1) * (tw + p.KW - 1) <= max_patch) { p.TH = th; p.TW = tw; p.TB = tb; }
+    if (sw.tile_set) {   // CVG_PATCH_TILE=th,tw,tb: tile override (benchmarking)
+        const int th = sw.tile[0], tw = sw.tile[1], tb = sw.tile[2];
+        if (th * tw * tb <= p.BM && tb * (th + p.KH - 1) * (tw + p.KW - 1) <= max_patch) { p.TH = th; p.TW = tw; p.TB = tb; }
     }
     if (!offsets_fit(d, p.TB)) return;
     p.PH = p.TH + p.KH - 1; p.PW = p.TW + p.KW - 1;
@@ -1255,8 +1471,7 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     p.lds_bytes = 2 * (size_t)patch_bytes;
     const size_t stage_bytes = (size_t)p.BM * (p.BN * es + 16);     // the output tile is staged over the patch buffers
     if (p.lds_bytes < stage_bytes) p.lds_bytes = stage_bytes;
-    static const char* extra = getenv("CVG_PATCH_LDS_EXTRA");      // occupancy experiments
-    if (extra) p.lds_bytes += (size_t)atoi(extra);
+    p.lds_bytes += (size_t)sw.lds_extra;                           // occupancy experiments
     // One image group per workgroup unless the layer qualifies for the walking form: eight-wave
     // workgroups (one per CU), whole groups only, at most one workgroup per CU in the grid and at least
     // two groups for each.  The workgroup then pays its set-up (address arithmetic, first patch, weight
@@ -1273,7 +1488,7 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
         const size_t need = 2 * (size_t)patch_bytes + stage_bytes;
         if (walks >= 2 && need + 8 * 1024 <= 160 * 1024) {            // + the statistics scratch of the kernel
             p.gstride = stride; p.stage_off = 2 * patch_bytes; p.lds_bytes = need; p.walk = 1;
-            if (persist && persist[0] == '2') p.gstride = p.groups;   // the walking kernel, one group each (benchmarking)
+            if (sw.patch_persist == '2') p.gstride = p.groups;        // the walking kernel, one group each (benchmarking)
         }
     }
     p.ok = 1;
@@ -1301,11 +1516,9 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     // (2 LDS cycles instead of 1), where the natural lane order spreads a group over 28 consecutive pixels
     // and collides up to three ways: measured -5..-7 % on the 8 x 8 layers and on the decoder's
     // input-gradient layers (10-, 18- and 66-pixel-wide grids), none slower.  CVG_PATCH_PERM=0: as before.
-    static const char* perm = getenv("CVG_PATCH_PERM");
-    a.lane_perm = (perm && perm[0] == '0') ? ((p.TW % 16 == 0) ? 1 : 0) : 1;
+    a.lane_perm = cvg_switches().patch_perm == '0' ? ((p.TW % 16 == 0) ? 1 : 0) : 1;
     {   // pixels per thread in the store phase: BM * (BN * es / 16) / threads
-        static const char* wide8 = getenv("CVG_PATCH_WIDE");
-        const bool four = wide8 && wide8[0] == '1';
+        const bool four = cvg_switches().patch_wide == '1';
         const int threads = (p.BN == 64 && p.BM == 128) ? 128 : ((p.BN == 128 && p.BM == 256 && !four) ? 512 : 256);
         const int pt = p.BM * (p.BN * es / 16) / threads;
         a.row_fast = (p.TW % pt == 0) ? 1 : 0;
@@ -1323,8 +1536,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
     if (d->dtype == CVG_BF16) {
         if (p.BN == 128 && p.BM == 256) {
-            static const char* w8 = getenv("CVG_PATCH_WIDE");
-            if (w8 && w8[0] == '1') return launch_patch_fwd<bf16, 2, 2, 4, 2>(p, a, s);
+            if (cvg_switches().patch_wide == '1') return launch_patch_fwd<bf16, 2, 2, 4, 2>(p, a, s);
             return launch_patch_fwd<bf16, 2, 4, 4, 1>(p, a, s);       // eight waves, 32 ch x 128 px each
         }
         if (p.BN == 128) return launch_patch_fwd<bf16, 1, 4, 4, 1>(p, a, s);
@@ -1354,7 +1566,7 @@ int patch_pack_launch(const cvg_conv_desc* d, const PatchPlan& p, const cvg_wmap
 // write and re-read half the partial slabs of two launches over 256 CUs one after the other.
 // CVG_WGRAD_WGS overrides (benchmarking).
 static int wgrad_target_wgs(const cvg_conv_desc* d) {
-    static const int forced = [] { const char* e = getenv("CVG_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+    const int forced = cvg_switches().wgrad_wgs;
     if (forced >= 16) return forced;
     const int share = d->co_launches > 1 ? d->co_launches : 1;
     return 256 / (share > 8 ? 8 : share);
@@ -1363,7 +1575,7 @@ static int wgrad_target_wgs(const cvg_conv_desc* d) {
 void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     p.ok = 0;
     p.stride = 1;
-    static const bool no_s2 = getenv("CVG_WGRAD_S2_GATHER") != nullptr;      // A/B switch for benchmarking
+    const bool no_s2 = cvg_switches().wgrad_s2_gather;
     if (!no_s2 && d->stride == 2 && d->tstep_y == 1 && d->tstep_x == 1 && d->dtype == CVG_BF16 && d->KW == 3 &&
         d->ntaps == 9 && d->N > 64 && d->Cin % CK == 0 && d->x_pix_pitch == d->Cin && d->pad_mode == CVG_PAD_ZERO &&
         choose_tile(d->B, d->OH, d->OW, 3, 3, 128, 592, p.TB, p.TH, p.TW, 2) && offsets_fit(d, p.TB)) {
@@ -1389,12 +1601,12 @@ void patch_wgrad_plan(const cvg_conv_desc* d, PatchWgradPlan& p) {
     const int es = d->dtype == CVG_BF16 ? 2 : 4;
     p.KW = d->KW; p.KH = d->ntaps / d->KW; p.T = d->ntaps;
     p.nine = 0;
-    static const bool no_nine = getenv("CVG_WGRAD_V1") != nullptr;           // A/B switch for benchmarking
+    const bool no_nine = cvg_switches().wgrad_v1;
     if (!no_nine && d->dtype == CVG_BF16 && d->KW == 3 && d->ntaps == 9 && d->N > 32 && d->x_pix_pitch == d->Cin &&
         d->pad_mode == CVG_PAD_ZERO) {
         // chunks per workgroup: two, with eight waves for wide layers (a dY tile then feeds twice the
         // MFMA work per byte fetched) and four waves for 64-channel ones
-        static const bool no8 = getenv("CVG_WGRAD_4W") != nullptr;            // A/B switch for benchmarking
+        const bool no8 = cvg_switches().wgrad_4w;
         const int wc = (d->N > 64 && (no8 || d->Cin % (2 * CK) != 0)) ? 1 : 2;
         const int wn9 = d->N > 64 ? 4 : 2;
         if (d->Cin % (CK * wc) == 0 &&
@@ -1475,8 +1687,7 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
         PatchWgradArgs b = a;
         b.nchunks = p.nchunks; b.nchunks_ntiles = p.nchunks * p.n_tiles;
         b.div_chunks = make_fastdiv(p.nchunks); b.div_cn = make_fastdiv(b.nchunks_ntiles);
-        static const bool no_remap = getenv("CVG_NO_XCD_REMAP") != nullptr;
-        b.xcd_remap = no_remap ? 0 : 1;
+        b.xcd_remap = cvg_switches().no_xcd_remap ? 0 : 1;
         const int64_t nwg = (int64_t)b.nchunks_ntiles * p.nsplit;
         if (nwg >= (1ll << 31)) CVG_FAIL("patch_wgrad: too many workgroups");
         if (p.stride == 2) {
@@ -1511,6 +1722,60 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
     const int64_t n = (int64_t)map->n_valid * (a.k_ld / 4);
     const int zg = wgrad_reduce_zg(n, p.nsplit);
     wgrad_reduce<<<ceil_div(n, 256 / zg), 256, 0, s>>>(ws, grad, *map, a.n_rows, a.k_ld, p.nsplit, accumulate, zg);
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- input gradient of the stride-2 convolutions (CVG_FORM_S2_TRANSPOSED) -------------------------------
+void patch_dgrad_s2_plan(const cvg_conv_desc* d, S2tPlan& p) {
+    p.ok = 0;
+    if (d->form != CVG_FORM_S2_TRANSPOSED || d->KW != 3 || d->ntaps != 9) return;
+    if (d->dtype != CVG_BF16 && d->dtype != CVG_F32) return;
+    const int es = d->dtype == CVG_BF16 ? 2 : 4;
+    if (d->Cin % CK != 0 || d->x_pix_pitch != d->Cin || d->N % (16 / es) != 0 || d->y_pix_pitch % (16 / es) != 0 ||
+        d->y_row_pitch % (16 / es) != 0 || d->y_img_pitch % (16 / es) != 0) return;
+    p.BN = (d->dtype == CVG_BF16 && d->N > 64) ? 128 : 64;
+    if (!choose_tile(d->B, d->H, d->W, 2, 2, 128, 256, p.TB, p.TH, p.TW)) return;
+    if (!offsets_fit(d, p.TB)) return;
+    p.tiles_y = ceil_div(d->H, p.TH); p.tiles_x = ceil_div(d->W, p.TW); p.groups = ceil_div(d->B, p.TB);
+    // a grid that leaves CUs without a 128-channel workgroup: 64-channel workgroups (two fit a CU) instead
+    if (p.BN == 128 && (int64_t)p.tiles_y * p.tiles_x * p.groups * ceil_div(d->N, 128) < 200) p.BN = 64;
+    p.patch_px = p.TB * (p.TH + 1) * (p.TW + 1);
+    p.nchunks = d->Cin / CK;
+    const double eff = (double)d->B * d->H * d->W / ((double)p.tiles_y * p.tiles_x * p.groups * 128);
+    if (eff < 0.25 || p.groups > 65535) return;
+    const size_t patch_bytes = ((size_t)p.patch_px * (CK * es + 16) + 255) & ~(size_t)255;
+    const size_t stage_bytes = (size_t)256 * (p.BN * es + 16);
+    p.lds_bytes = 2 * patch_bytes > stage_bytes ? 2 * patch_bytes : stage_bytes;
+    p.ok = 1;
+}
+
+int patch_dgrad_s2_launch(const cvg_conv_desc* d, const S2tPlan& p, const void* dy, const void* w, void* dx,
+                          const void* gate, hipStream_t s) {
+    S2tArgs a;
+    const int es = d->dtype == CVG_BF16 ? 2 : 4;
+    a.x = dy; a.wf = w; a.y = dx; a.gate = gate;
+    a.B = d->B; a.H = d->H; a.W = d->W;
+    a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch; a.x_pix_pitch = d->x_pix_pitch;
+    a.N = d->N; a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
+    a.nchunks = p.nchunks; a.patch_px = p.patch_px;
+    a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
+    a.lane_perm = 1;
+    fill_tile(a.t, p.TB, p.TH, p.TW, 2, 2, p.tiles_x);
+    const int threads = p.BN == 128 ? 512 : 256;
+    const int pt = 256 * (p.BN * es / 16) / threads;                 // staged rows per thread in the store phase
+    a.row_fast = ((2 * p.TW) % pt == 0) ? 1 : 0;
+    const dim3 grid(p.tiles_y * p.tiles_x, ceil_div(d->N, p.BN), p.groups);
+    if (d->dtype == CVG_BF16 && p.BN == 128) {
+        if (set_lds(patch_dgrad_s2<bf16, 2, 4>, p.lds_bytes)) return -1;
+        patch_dgrad_s2<bf16, 2, 4><<<grid, 512, p.lds_bytes, s>>>(a);
+    } else if (d->dtype == CVG_BF16) {
+        if (set_lds(patch_dgrad_s2<bf16, 2, 2>, p.lds_bytes)) return -1;
+        patch_dgrad_s2<bf16, 2, 2><<<grid, 256, p.lds_bytes, s>>>(a);
+    } else {
+        if (set_lds(patch_dgrad_s2<float, 2, 2>, p.lds_bytes)) return -1;
+        patch_dgrad_s2<float, 2, 2><<<grid, 256, p.lds_bytes, s>>>(a);
+    }
     CVG_LAUNCH_CHECK();
     return 0;
 }

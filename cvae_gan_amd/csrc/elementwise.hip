@@ -1140,7 +1140,7 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     CVG_CHECK(x && stats && ws, "bn_stats: null");
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
-    static const bool raw_sums = getenv("CVG_BN_RAW_SUMS") != nullptr;       // A/B switch: sums about 0
+    const bool raw_sums = cvg_switches().bn_raw_sums;       // A/B switch: sums about 0
     float* shift = raw_sums ? nullptr : stats + C;      // parked in the slot the finalize overwrites last
     RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, shift, M, C, C, red_blocks(M, Cb), Cb};
     DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));

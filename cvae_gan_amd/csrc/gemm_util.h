@@ -33,6 +33,23 @@ template <> struct TrLoad<float> {
 // For T = float the slot (h, j) holds pixel 2j+h, for bf16 pixel 8h+j; both operands
 // of one MFMA use the same loader, so the products pair up correctly.
 
+// One staged 16-byte piece times LeakyReLU'(g) per element (g > 0 ? 1 : slope), rounded once more to T.
+template <typename T> __device__ __forceinline__ u32x4 mul_gate(u32x4 v, u32x4 g);
+template <> __device__ __forceinline__ u32x4 mul_gate<float>(u32x4 v, u32x4 g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(__uint_as_float(g[j]) > 0.f)) v[j] = __float_as_uint(__uint_as_float(v[j]) * LRELU_SLOPE);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 mul_gate<bf16>(u32x4 v, u32x4 g) {
+    bf16x8 vb = __builtin_bit_cast(bf16x8, v);
+    const bf16x8 gb = __builtin_bit_cast(bf16x8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (!((float)gb[j] > 0.f)) vb[j] = (__bf16)((float)vb[j] * LRELU_SLOPE);
+    return __builtin_bit_cast(u32x4, vb);
+}
+
 // ---- canonical <-> GEMM layout map ---------------------------------------------
 __device__ __forceinline__ int wmap_index(const cvg_wmap& m, int n, int k) {
     if (n >= m.n_valid) return -1;

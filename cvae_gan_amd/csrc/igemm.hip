@@ -66,23 +66,6 @@ __device__ __forceinline__ bool pad_coord(const Geom& g, int& iy, int& ix) {
 // ================================================================================
 // forward / input-gradient kernel
 // ================================================================================
-// One staged 16-byte piece times LeakyReLU'(g) per element (g > 0 ? 1 : slope), rounded once more to T.
-template <typename T> __device__ __forceinline__ u32x4 mul_gate(u32x4 v, u32x4 g);
-template <> __device__ __forceinline__ u32x4 mul_gate<float>(u32x4 v, u32x4 g) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (!(__uint_as_float(g[j]) > 0.f)) v[j] = __float_as_uint(__uint_as_float(v[j]) * LRELU_SLOPE);
-    return v;
-}
-template <> __device__ __forceinline__ u32x4 mul_gate<bf16>(u32x4 v, u32x4 g) {
-    bf16x8 vb = __builtin_bit_cast(bf16x8, v);
-    const bf16x8 gb = __builtin_bit_cast(bf16x8, g);
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (!((float)gb[j] > 0.f)) vb[j] = (__bf16)((float)vb[j] * LRELU_SLOPE);
-    return __builtin_bit_cast(u32x4, vb);
-}
-
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_fwd_tile(const FwdArgs& a, const int zsplit) {
     constexpr int VEC = Elem<T>::VEC;
@@ -540,8 +523,7 @@ __global__ void __launch_bounds__(256) weight_pack_batch(const cvg_pack_job* __r
 int elem_size(int dtype) { return dtype == CVG_BF16 ? 2 : 4; }
 
 bool patch_enabled() {
-    static const bool on = getenv("CVG_NO_PATCH") == nullptr;     // A/B switch for benchmarking
-    return on;
+    return !cvg_switches().no_patch;
 }
 
 int make_geom(const cvg_conv_desc* d, Geom& g) {
@@ -681,6 +663,15 @@ size_t cvg_conv_fwd_workspace(const cvg_conv_desc* d) {
 int cvg_conv_fwd(const cvg_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                  const float* cbias, const int32_t* labels, const void* res, const void* gate, void* ws,
                  size_t ws_bytes, cvg_stream stream) {
+    if (d && d->form == CVG_FORM_S2_TRANSPOSED) {
+        S2tPlan sp;
+        patch_dgrad_s2_plan(d, sp);
+        CVG_CHECK(sp.ok, "conv_fwd: this transposed stride-2 geometry is not supported (dY channels must be a multiple of "
+                  "32, dX channels of 8); use four cvg_conv_fwd_group classes");
+        CVG_CHECK(x && w && y, "conv_fwd: null tensor");
+        CVG_CHECK(!bias && !cbias && !res, "conv_fwd: the transposed stride-2 form takes no bias / res");
+        return patch_dgrad_s2_launch(d, sp, x, w, y, gate, (hipStream_t)stream);
+    }
     FwdArgs a;
     if (make_geom(d, a.g)) return -1;
     const int BK = bk_of(d->dtype);
@@ -795,6 +786,11 @@ int cvg_conv_wgrad_strided(const cvg_conv_desc* d, const void* x, const void* dy
 }
 
 const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {
+    if (d->form == CVG_FORM_S2_TRANSPOSED) {
+        S2tPlan sp;
+        patch_dgrad_s2_plan(d, sp);
+        return sp.ok ? "patch_dgrad_s2" : "unsupported";
+    }
     if (patch_enabled()) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
@@ -861,6 +857,14 @@ int cvg_weight_pack(const cvg_conv_desc* d, const cvg_wmap* map, const float* ca
     CVG_CHECK(d && map && canonical && packed && d->w_rows > 0 && d->w_ld > 0, "weight_pack: bad args");
     CVG_CHECK(map->kd > 0 && map->nd > 0, "weight_pack: bad map");
     hipStream_t s = (hipStream_t)stream;
+    if (d->form == CVG_FORM_S2_TRANSPOSED) {
+        S2tPlan sp;
+        patch_dgrad_s2_plan(d, sp);
+        CVG_CHECK(sp.ok, "weight_pack: unsupported transposed stride-2 geometry");
+        PatchPlan pp;
+        pp.nchunks = sp.nchunks; pp.T = 9;
+        return patch_pack_launch(d, pp, map, canonical, packed, s);
+    }
     if (patch_enabled()) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
@@ -882,7 +886,14 @@ int cvg_weight_pack_job(const cvg_conv_desc* d, const cvg_wmap* map, const float
     job->block0 = block0; job->dtype = d->dtype; job->Cin = d->Cin;
     job->rows = d->w_rows; job->ld = d->w_ld; job->mode = 0; job->nchunks = 0; job->ntaps = d->ntaps;
     int64_t n = (int64_t)d->w_rows * d->w_ld;
-    if (patch_enabled()) {
+    if (d->form == CVG_FORM_S2_TRANSPOSED) {
+        S2tPlan sp;
+        patch_dgrad_s2_plan(d, sp);
+        CVG_CHECK(sp.ok, "weight_pack_job: unsupported transposed stride-2 geometry");
+        CVG_CHECK((int64_t)sp.nchunks * 9 * 32 <= d->w_ld, "weight_pack_job: packed buffer too small");
+        job->mode = 1; job->nchunks = sp.nchunks; job->ntaps = 9;
+        n = (int64_t)d->w_rows * sp.nchunks * 9 * 32;
+    } else if (patch_enabled()) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
         if (pp.ok) {

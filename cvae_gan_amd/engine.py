@@ -27,7 +27,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import ConvDesc, WMap, PAD_ZERO, PAD_REFLECT
+from ._lib import ConvDesc, WMap, PAD_ZERO, PAD_REFLECT, FORM_S2_TRANSPOSED, CONV_ALONE
 
 # Checkpoint key prefixes.  The reference saves self.En.module.state_dict() (models/cvae.py:234-235):
 # En.module is the `encoder` wrapper, whose one child attribute is `self.encoder` (the inner
@@ -262,6 +262,10 @@ class Engine:
         self.s = pix_dim // (2 ** n_stage)
         self._gemms, self._ws_bytes = [], 0
         self.overlap = os.environ.get("CVG_NO_OVERLAP") is None     # A/B switch for benchmarking
+        self.fused_s2_dgrad = os.environ.get("CVG_S2_DGRAD_CLASSES") is None    # A/B: four gather convolutions instead
+        # the forward pass runs on one stream with nothing beside it (the weight-gradient side streams only exist
+        # in backward): its convolutions may keep their workgroups resident (see CVG_CONV_ALONE)
+        self._fwd_flags = CONV_ALONE if os.environ.get("CVG_NO_FWD_WALK") is None else 0
         self._side, self._side_dirty = None, False
         self._wgrad_descs = []          # weight-gradient-only descriptors (workspace sizing)
         self._pack_batch = None
@@ -388,12 +392,19 @@ class Engine:
         OH = H // stride
         fwd = _Gemm(self, _desc(T, B, H, H, cin, OH, OH, cout, 3, 9, stride=stride, off=(-1, -1)),
                     _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key)
+        fwd.desc.flags = self._fwd_flags
         if stride == 1:
             dg = [_Gemm(self, _desc(T, B, H, H, cout, H, H, cin, 3, 9, off=(-1, -1)),
                         _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key)]
         else:
-            # transposed stride-2 conv split by output parity: rows 2a+py receive
-            # kh = 1 (from dY row a) when py = 0, kh = 0 (row a+1) and kh = 2 (row a) when py = 1
+            # transposed stride-2 conv.  Preferred: one launch over the dY grid whose nine taps each feed the
+            # accumulators of their own output-parity class (rows 2a+py receive kh = 1 (from dY row a) when
+            # py = 0, kh = 0 (row a+1) and kh = 2 (row a) when py = 1; columns likewise)
+            dt = _desc(T, B, OH, OH, cout, OH, OH, cin, 3, 9, y_dims=(H, H))
+            dt.form = FORM_S2_TRANSPOSED
+            if self.fused_s2_dgrad and ops.conv_fwd_kernel(dt) == "patch_dgrad_s2":
+                return fwd, [_Gemm(self, dt, _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9), key)]
+            # otherwise (narrow test networks): the four classes as separate gather convolutions in one launch
             dg = []
             for py in (0, 1):
                 for px in (0, 1):
@@ -442,7 +453,8 @@ class Engine:
             blk["conv1"], blk["dg1"] = self._conv3x3_plans(p + "res.res.0.weight", B, H, cin, cin, 1)
             blk["conv2"], blk["dg2"] = self._conv3x3_plans(p + "res.res.3.weight", B, H, cin, cin, 1)
             blk["down"], blk["dgd"] = self._conv3x3_plans(p + "conv.weight", B, H, cin, cout, 2)
-            blk["dgd_group"] = ops.ConvGroup([g.desc for g in blk["dgd"]], [g.w for g in blk["dgd"]])
+            blk["dgd_group"] = (ops.ConvGroup([g.desc for g in blk["dgd"]], [g.w for g in blk["dgd"]])
+                                if len(blk["dgd"]) > 1 else None)
             for name in ("c1", "b1", "c2", "r", "d_r", "d_c2", "d_b1", "d_c1"):
                 blk[name] = self._t(M, cin)
             blk["st1"], blk["st2"] = self._f(2, cin), self._f(2, cin)
@@ -510,6 +522,7 @@ class Engine:
             # valid 3x3 conv on the up-sampled, reflection-padded tensor U
             up["fwd"] = _Gemm(self, _desc(T, B, U, U, cin, 2 * h, 2 * h, cout, 3, 9),
                               _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key + "weight")
+            up["fwd"].desc.flags = self._fwd_flags
             # dU = full correlation of dY with the flipped kernel (zero padding 2)
             up["dg"] = _Gemm(self, _desc(T, B, 2 * h, 2 * h, cout, U, U, cin, 3, 9, off=(-2, -2)),
                              _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key + "weight")
@@ -832,7 +845,10 @@ class Engine:
             self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"])
         # d_r: gradient of the block's pre-activation sum (the stride-2 input gradient times
         # LeakyReLU'(r), applied as that kernel stores): r is read once, not by all three consumers
-        blk["dgd_group"].run(blk["d_out"], blk["d_r"], gate=blk["r"])
+        if blk["dgd_group"] is None:
+            self._fwd(blk["dgd"][0], blk["d_out"], blk["d_r"], gate=blk["r"])
+        else:
+            blk["dgd_group"].run(blk["d_out"], blk["d_r"], gate=blk["r"])
         self._bn_bwd(blk["d_r"], None, blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4", gated=True)
         with self._branch():
             self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C)

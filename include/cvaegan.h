@@ -28,6 +28,8 @@ extern "C" {
 typedef void* cvg_stream;            /* a hipStream_t */
 enum { CVG_F32 = 0, CVG_BF16 = 1 };
 enum { CVG_PAD_ZERO = 0, CVG_PAD_REFLECT = 1 };
+enum { CVG_FORM_GATHER = 0, CVG_FORM_S2_TRANSPOSED = 1 };
+enum { CVG_CONV_ALONE = 1 };
 
 int         cvg_version(void);
 const char* cvg_last_error(void);
@@ -62,6 +64,21 @@ typedef struct cvg_conv_desc {
                                         by side on different streams (0 or 1: one).  Each then aims for
                                         1/co_launches of the CUs, i.e. that fraction of the split count
                                         and of the partial-slab traffic                              */
+    int32_t form;                    /* CVG_FORM_GATHER: the geometry above.
+                                        CVG_FORM_S2_TRANSPOSED: the INPUT GRADIENT of a 3x3, stride-2,
+                                        zero-padding-1 convolution (ConvResBlock's down conv,
+                                        networks.py:209-210) in one launch: x = dY [B][H][W][Cin] (Cin = that
+                                        convolution's output channels, a multiple of 32), y = dX
+                                        [B][2H][2W][N] through the y pitches; kernel tap (kh, kw) adds
+                                        dY[a + (kh == 0)][b + (kw == 0)] * W[.][n][kh][kw] to
+                                        dX[2a + (kh != 1)][2b + (kw != 1)][n] (rows / columns of dY beyond H / W
+                                        read 0).  KW = 3, ntaps = 9, weights packed by cvg_weight_pack*
+                                        with k = tap * Cin + c; stride, tstep, off, o*_mul / o*_off are
+                                        ignored; no bias / cbias / res, gate scales the output.  Only where
+                                        cvg_conv_fwd_kernel() names "patch_dgrad_s2".                  */
+    int32_t flags;                   /* CVG_CONV_ALONE: no other launch runs beside this one (a forward pass on
+                                        one stream): the forward kernel may then keep one workgroup resident
+                                        per CU and let it walk over several image groups                  */
 } cvg_conv_desc;
 
 /* Conv2d / Linear forward and input-gradient.

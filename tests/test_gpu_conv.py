@@ -119,12 +119,13 @@ def test_conv_bias_residual_gate(dtype):
     assert relmax(from_rows(yr, B, H, H, cout), ref) < TOL[dtype]
 
 
-def test_walking_workgroups_bit_identical(monkeypatch):
-    """CVG_PATCH_PERSIST=1: eight-wave workgroups of patch_fwd keep their tile position and walk over several
+def test_walking_workgroups_bit_identical():
+    """CVG_CONV_ALONE: eight-wave workgroups of patch_fwd keep their tile position and walk over several
     image groups (bias preloaded, residual fetched after the staging, output staged behind the patch buffers).
     Same products in the same order: the output must equal the default form's bit for bit, with bias,
     residual and gate, and with a group count that the walks do not divide (130 images over 44 phases)."""
     ops, _desc, _wmap = _mods()
+    from cvae_gan_amd._lib import CONV_ALONE
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(11)
     B, H, cin, cout = 130, 32, 64, 128
@@ -138,17 +139,17 @@ def test_walking_workgroups_bit_identical(monkeypatch):
     wm = _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9)
     xr, rr, gr, pk = to_rows(x, dtype), to_rows(res, dtype), to_rows(gate, dtype), pack(ops, wm, w, d, dtype)
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CVG_PATCH_PERSIST", mode)
+    for flags in (0, CONV_ALONE):
+        d.flags = flags
         for with_res in (False, True):
             yr = torch.zeros(B * H * H, cout, dtype=dtype, device="cuda")
             ops.conv_fwd(d, xr, pk, yr, bias=bias.cuda(), res=rr if with_res else None, gate=gr if with_res else None,
                          ws=ws_for(ops, d))
             torch.cuda.synchronize()
-            out[mode, with_res] = yr
-    assert relmax(from_rows(out["1", True], B, H, H, cout), ref) < TOL[dtype]
-    assert torch.equal(out["0", True], out["1", True])
-    assert torch.equal(out["0", False], out["1", False])
+            out[flags, with_res] = yr
+    assert relmax(from_rows(out[CONV_ALONE, True], B, H, H, cout), ref) < TOL[dtype]
+    assert torch.equal(out[0, True], out[CONV_ALONE, True])
+    assert torch.equal(out[0, False], out[CONV_ALONE, False])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -177,6 +178,52 @@ def test_conv_output_gate(dtype):
         x1 = torch.zeros(2 * 64, 32, dtype=dtype, device="cuda")
         with pytest.raises(RuntimeError, match="gather kernel only"):
             ops.conv_fwd(d1, x1, pack(ops, wm1, w1, d1, dtype), y1, gate=y1, ws=ws_for(ops, d1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,cin,cout", [(3, 12, 16, 32), (2, 16, 64, 128), (5, 8, 128, 256), (9, 4, 32, 32),
+                                          (70, 2, 64, 64), (3, 40, 72, 64), (2, 64, 64, 128)])
+def test_s2_input_gradient_one_launch(dtype, B, H, cin, cout):
+    """CVG_FORM_S2_TRANSPOSED: the input gradient of a 3x3 stride-2 convolution with all four output-parity classes
+    in one launch, against autograd, with and without the LeakyReLU gate on the output; tiles that hold several
+    images, ragged tiles (40 -> 20 x 20 grid), channel counts off the 64 / 128 tile and a 1 x 1 dY grid."""
+    ops, _desc, _wmap = _mods()
+    from cvae_gan_amd._lib import FORM_S2_TRANSPOSED
+    g = torch.Generator().manual_seed(B * 100 + H + cin)
+    x = torch.randn(B, cin, H, H, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    if dtype == torch.bfloat16:
+        w = w.bfloat16().float()
+    OH = H // 2
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    gate = torch.randn(B, cin, H, H, generator=g)
+    if dtype == torch.bfloat16:
+        dy, gate = dy.bfloat16().float(), gate.bfloat16().float()
+    y.backward(dy)
+    d = _desc(dtype, B, OH, OH, cout, OH, OH, cin, 3, 9, y_dims=(H, H))
+    d.form = FORM_S2_TRANSPOSED
+    assert ops.conv_fwd_kernel(d) == "patch_dgrad_s2"
+    wm = _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9)
+    pk = pack(ops, wm, w, d, dtype)
+    dyr = to_rows(dy, dtype)
+    for with_gate in (False, True):
+        dxr = torch.full((B * H * H, cin), 7.0, dtype=dtype, device="cuda")
+        ops.conv_fwd(d, dyr, pk, dxr, gate=to_rows(gate, dtype) if with_gate else None)
+        torch.cuda.synchronize()
+        ref = x.grad * (torch.where(gate > 0, 1.0, 0.2) if with_gate else 1.0)
+        assert relmax(from_rows(dxr, B, H, H, cin), ref) < TOL[dtype]
+
+
+def test_s2_input_gradient_rejects_unsupported():
+    ops, _desc, _wmap = _mods()
+    from cvae_gan_amd._lib import FORM_S2_TRANSPOSED
+    d = _desc(torch.bfloat16, 2, 4, 4, 16, 4, 4, 8, 3, 9, y_dims=(8, 8))       # 16 dY channels: not a multiple of 32
+    d.form = FORM_S2_TRANSPOSED
+    assert ops.conv_fwd_kernel(d) == "unsupported"
+    t = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.conv_fwd(d, t, t, t)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

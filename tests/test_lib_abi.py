@@ -77,5 +77,5 @@ def test_size_and_padding_limits_are_rejected_without_a_gpu():
 
 def test_struct_layout_matches_header():
     from cvae_gan_amd import _lib
-    assert C.sizeof(_lib.ConvDesc) == 29 * 4
+    assert C.sizeof(_lib.ConvDesc) == 31 * 4
     assert C.sizeof(_lib.WMap) == 12 * 4 + 64 * 2
