@@ -18,6 +18,7 @@ F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 FORM_GATHER, FORM_S2_TRANSPOSED = 0, 1
 CONV_ALONE = 1
+WS_HEADER = 40960        # floats of arrival counters at the start of a reduction workspace (CVG_WS_HEADER)
 
 
 class ConvDesc(C.Structure):

@@ -34,6 +34,7 @@ struct CvgSwitches {
     bool wgrad_v1;            // CVG_WGRAD_V1: tap-split weight-gradient kernel instead of the nine-tap one
     bool wgrad_4w;            // CVG_WGRAD_4W: four-wave nine-tap weight-gradient workgroups
     bool bn_raw_sums;         // CVG_BN_RAW_SUMS: BatchNorm sums about 0 instead of about row 0
+    bool split_finalize;      // CVG_SPLIT_FINALIZE: column reductions finish in a second kernel instead of in the same launch
     char patch_wide;          // CVG_PATCH_WIDE: '0' no eight-wave tiles, '1' 64-channel wave tiles
     char patch_persist;       // CVG_PATCH_PERSIST: '0' no walking workgroups, '1' on every eligible layer, '2' the
                               // walking kernel with one image group per workgroup; unset: the descriptor's flag

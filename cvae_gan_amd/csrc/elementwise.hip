@@ -26,7 +26,36 @@ struct RedArgs {
     float* shift_out;    // STATS: [C] receives the shift the sums are taken about (row 0), or null
     int M, C, ld, nblk;
     int Cb;              // columns handled per blockIdx.y (== C unless C > 1024; the last block may be ragged)
+    // Totals in the same launch (fin != FIN_NONE): the block partials meet in two levels behind arrival counters
+    // (groups of FIN_GROUP consecutive blocks, then the groups), each level summed in index order by whichever
+    // block arrives last, so the totals do not depend on the arrival order and no second kernel is needed.
+    int fin;             // FIN_NONE, FIN_STATS (mean / invstd / running statistics), FIN_SUMS (out0 / out1)
+    double* ws2;         // level-2 partials [2][ngroups][C]
+    unsigned* tickets;   // [gridDim.y][ngroups + 1] arrival counters, zero before and after every launch
+    float* out0; float* out1; int md, ma, mb;                      // FIN_SUMS: out0[(c / md) * ma + (c % md) * mb], out1[c]
+    float* stats_out; float* running_mean; float* running_var; long long* nbt;   // FIN_STATS
 };
+enum { FIN_NONE = 0, FIN_STATS = 1, FIN_SUMS = 2 };
+constexpr int FIN_GROUP = 16;
+
+// Loads that read past the per-XCD L2 (sc1: coherent at agent scope).  The compiler completes every atomic load
+// before it issues the next one; these are issued back to back instead and completed together by ld_agent_wait,
+// which also carries the values, so that nothing uses one before the wait.
+__device__ __forceinline__ float ld_agent(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <typename V, int N>
+__device__ __forceinline__ void ld_agent_wait(V (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i]) : : "memory");
+}
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
@@ -61,7 +90,8 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
         load8<T>((const T*)a.x + c_off + chunk * 8, shift);
         if (blockIdx.x == 0 && rl == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a.shift_out[c_off + chunk * 8 + j] = shift[j];
+            for (int j = 0; j < 8; ++j)
+                __hip_atomic_store(&a.shift_out[c_off + chunk * 8 + j], shift[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (rl < RL && col_ok) {
@@ -117,7 +147,91 @@ __global__ void __launch_bounds__(256) colreduce(const RedArgs a) {
         const int ch = col / 8, j = col % 8;
         float s = 0.f;
         for (int r = 0; r < RL; ++r) s += sm[which][r * CC + ch][j];
-        if (c_off + col < a.C) a.ws[((size_t)which * a.nblk + blockIdx.x) * a.C + c_off + col] = s;
+        if (c_off + col < a.C)
+            __hip_atomic_store(&a.ws[((size_t)which * a.nblk + blockIdx.x) * a.C + c_off + col], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.fin == FIN_NONE) return;
+
+    // ---- totals: the last block of each group of FIN_GROUP sums the group's rows, the last group the groups.
+    // Everything that crosses workgroups here (partial rows, level-2 rows, the shift row, counters) is written and
+    // read with agent-scope atomic accesses: those write through / read past the per-XCD L2, so no cache-wide
+    // release / acquire fence is needed (one such fence costs ~10 us on this part, and four of them would sit on
+    // the critical path of the last block).  A writer waits for its stores to be acknowledged before it counts
+    // itself in; a reader loads only after it has seen the full count.
+    __shared__ int role;
+    const int ngroups = (a.nblk + FIN_GROUP - 1) / FIN_GROUP;
+    const int grp = blockIdx.x / FIN_GROUP, g_beg = grp * FIN_GROUP;
+    const int g_cnt = min(FIN_GROUP, a.nblk - g_beg);
+    unsigned* tk = a.tickets + (size_t)blockIdx.y * (ngroups + 1);
+    __builtin_amdgcn_s_waitcnt(0);                   // this thread's partial stores have been acknowledged ...
+    __syncthreads();
+    if (threadIdx.x == 0)                            // ... before the block is counted
+        role = __hip_atomic_fetch_add(&tk[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(g_cnt - 1) ? 1 : 0;
+    __syncthreads();
+    if (!role) return;
+    for (int t = threadIdx.x; t < 2 * a.Cb; t += blockDim.x) {
+        const int which = t / a.Cb, col = t % a.Cb;
+        if (c_off + col >= a.C) continue;
+        const float* p = a.ws + ((size_t)which * a.nblk + g_beg) * a.C + c_off + col;
+        float v[FIN_GROUP];
+#pragma unroll
+        for (int r = 0; r < FIN_GROUP; ++r) {        // all loads in flight together
+            v[r] = 0.f;
+            if (r < g_cnt) v[r] = ld_agent(p + (size_t)r * a.C);
+        }
+        ld_agent_wait(v);
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < FIN_GROUP; ++r) acc += (double)v[r];
+        __hip_atomic_store(&a.ws2[((size_t)which * ngroups + grp) * a.C + c_off + col], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&tk[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // ready for the next launch
+        role = __hip_atomic_fetch_add(&tk[ngroups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ngroups - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!role) return;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&tk[ngroups], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.fin == FIN_STATS && a.nbt && blockIdx.y == 0) *a.nbt += 1;
+    }
+    for (int col = threadIdx.x; col < a.Cb; col += blockDim.x) {
+        const int c = c_off + col;
+        if (c >= a.C) continue;
+        double s = 0.0, ss = 0.0;
+        for (int g0 = 0; g0 < ngroups; g0 += 8) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = vb[u] = 0.0;
+                if (g0 + u < ngroups) {
+                    va[u] = ld_agent(&a.ws2[(size_t)(g0 + u) * a.C + c]);
+                    vb[u] = ld_agent(&a.ws2[((size_t)ngroups + g0 + u) * a.C + c]);
+                }
+            }
+            ld_agent_wait(va);
+            ld_agent_wait(vb);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += va[u]; ss += vb[u]; }
+        }
+        if (a.fin == FIN_STATS) {
+            const double dm = s / a.M;
+            const double mean = dm + (a.shift_out ? (double)__hip_atomic_load(&a.shift_out[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
+            double var = ss / a.M - dm * dm;
+            if (var < 0.0) var = 0.0;
+            a.stats_out[c] = (float)mean;
+            a.stats_out[a.C + c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+            if (a.running_mean) {
+                const double unb = a.M > 1 ? var * ((double)a.M / (a.M - 1)) : var;
+                a.running_mean[c] = (1.f - BN_MOMENTUM) * a.running_mean[c] + BN_MOMENTUM * (float)mean;
+                a.running_var[c] = (1.f - BN_MOMENTUM) * a.running_var[c] + BN_MOMENTUM * (float)unb;
+            }
+        } else {
+            a.out0[(c / a.md) * a.ma + (c % a.md) * a.mb] = (float)s;
+            if (a.out1) a.out1[c] = (float)ss;
+        }
     }
 }
 
@@ -1096,17 +1210,38 @@ __global__ void counter_tick(long long* c) {
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------
+int col_block_of(int C) { return C <= 1024 ? C : 512; }
 int red_threads(int C) { const int CC = C / 8; return CC * (256 / CC); }
 int red_blocks(int M, int C) {
     const int RL = 256 / (C / 8);
     int nb = ceil_div(M, (int64_t)RL * 8);
     return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
 }
+// Workspace of a reduction over rows[M][C], in floats: CVG_WS_HEADER arrival counters ([column blocks][ngroups + 1],
+// at the start so that calls with different shapes that share one workspace never write data over them), block
+// partials [2][nblk][C], level-2 partials (doubles) [2][ngroups][C].
+int red_groups(int nblk) { return ceil_div(nblk, FIN_GROUP); }
+int red_counters(int C, int nblk) { return ceil_div(C, col_block_of(C)) * (red_groups(nblk) + 1); }
+int red_rows(int M, int C) {                        // rows R such that 2 * R * C floats hold all of it
+    const int nblk = red_blocks(M, col_block_of(C)), ng = red_groups(nblk);
+    return nblk + 2 * ng + ceil_div(CVG_WS_HEADER, 2 * C);
+}
+// Points `a` at a workspace of red_rows(M, C) rows starting at ws and arms the in-launch totals.  Shapes with more
+// column blocks than the header has counters for (C > 600000) keep fin == FIN_NONE: the caller then launches the
+// separate finalize kernel.
+int red_finalize_setup(RedArgs& a, float* ws, int fin, const char* who) {
+    CVG_CHECK(((uintptr_t)ws & 7) == 0, "%s: the workspace must be 8-byte aligned", who);
+    a.ws = ws + CVG_WS_HEADER;
+    a.fin = (red_counters(a.C, a.nblk) <= CVG_WS_HEADER && !cvg_switches().split_finalize) ? fin : FIN_NONE;
+    a.ws2 = (double*)(a.ws + (size_t)2 * a.nblk * a.C);
+    a.tickets = (unsigned*)ws;
+    return 0;
+}
 int check_rows(const char* who, int M, int C) {
     CVG_CHECK(M > 0 && C >= 8 && C % 8 == 0 && C <= 65535 * 512, "%s: M %d C %d (C must be a positive multiple of 8)", who, M, C);
     return 0;
 }
-int col_block(int C) { return C <= 1024 ? C : 512; }
+int col_block(int C) { return col_block_of(C); }
 int grid1(int64_t n, int per = 256) { return ceil_div(n, per); }
 
 }  // namespace
@@ -1132,7 +1267,7 @@ int cvg_image_u8_to_f32(const uint8_t* hwc, float* nchw, int32_t B, int32_t P, c
     return 0;
 }
 
-int32_t cvg_bn_stats_blocks(int32_t M, int32_t C) { return red_blocks(M, col_block(C)); }
+int32_t cvg_bn_stats_blocks(int32_t M, int32_t C) { return red_rows(M, C); }
 
 int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats, float* running_mean,
                  float* running_var, int64_t* nbt, float* ws, cvg_stream stream) {
@@ -1143,10 +1278,14 @@ int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stat
     const bool raw_sums = cvg_switches().bn_raw_sums;       // A/B switch: sums about 0
     float* shift = raw_sums ? nullptr : stats + C;      // parked in the slot the finalize overwrites last
     RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, shift, M, C, C, red_blocks(M, Cb), Cb};
+    if (red_finalize_setup(a, ws, FIN_STATS, "bn_stats")) return -1;
+    a.stats_out = stats; a.running_mean = running_mean; a.running_var = running_var; a.nbt = (long long*)nbt;
     DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt, shift);
-    CVG_LAUNCH_CHECK();
+    if (a.fin == FIN_NONE) {
+        stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(a.ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt, shift);
+        CVG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1160,8 +1299,8 @@ int cvg_bn_stats_finalize(const float* partials, int32_t nblk, int32_t M, int32_
 }
 
 // ---- cvg_bn_stats without a workspace argument: the partials live in a static device array ----------
-constexpr int STATIC_MAX_C = 1024, STATIC_MAX_BLK = 512;       // red_blocks() never exceeds 512
-static __device__ __align__(256) float scratch[2 * STATIC_MAX_BLK * STATIC_MAX_C];      // 4 MiB per GPU
+constexpr int STATIC_MAX_C = 1024, STATIC_MAX_ROWS = 576;      // 512 block rows + 2 * 32 rows of level-2 doubles
+static __device__ __align__(256) float scratch[CVG_WS_HEADER + 2 * STATIC_MAX_ROWS * STATIC_MAX_C];     // 4.7 MiB per GPU
 
 // The array's device address, looked up once per device with that device current.  In host code the
 // name `scratch` is only a handle for this lookup: every launch below takes the returned pointer.
@@ -1190,12 +1329,15 @@ int cvg_bn_stats_static(const void* x, int32_t dtype, int32_t M, int32_t C, floa
     float* ws = nullptr;
     if (static_scratch(&ws)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    // every partial [which][block][channel] that stats_finalize reads is written by colreduce first, so
-    // nothing left in the array by an earlier call is ever read: no clearing needed
+    // Every partial that is read was written by this launch first, so nothing left in the array by an earlier
+    // call is ever read; the arrival counters at the start of the array are zero in the library's image and
+    // every launch leaves them at zero: no clearing needed.
+    CVG_CHECK((size_t)2 * red_rows(M, C) * C <= sizeof(scratch) / sizeof(float) + 2 * C,
+              "bn_stats_static: internal: workspace of %d rows", red_rows(M, C));
     RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, stats + C, M, C, C, red_blocks(M, C), C};
+    if (red_finalize_setup(a, ws, FIN_STATS, "bn_stats_static")) return -1;
+    a.stats_out = stats; a.running_mean = running_mean; a.running_var = running_var; a.nbt = (long long*)nbt;
     DISPATCH(dtype, colreduce<T, RED_STATS><<<dim3(a.nblk, 1), red_threads(C), 0, s>>>(a));
-    CVG_LAUNCH_CHECK();
-    stats_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, M, C, stats, running_mean, running_var, (long long*)nbt, stats + C);
     CVG_LAUNCH_CHECK();
     return 0;
 }
@@ -1236,13 +1378,17 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
     const int Cb = col_block(C);
     RedArgs a = {x, dy, y, stats, gamma, beta, ws, nullptr, M, C, C, red_blocks(M, Cb), Cb};
     const int gate = y ? 0 : (beta ? 1 : 2);     // no y and no beta: dy is already gated
+    if (red_finalize_setup(a, ws, FIN_SUMS, "bn_act_bwd")) return -1;
+    a.out0 = dbeta; a.out1 = dgamma; a.md = 1; a.ma = 1; a.mb = 0;
     const dim3 rgrid(a.nblk, ceil_div(C, Cb));
     if (gate == 0) DISPATCH(dtype, colreduce<T, RED_BNBWD><<<rgrid, red_threads(Cb), 0, s>>>(a));
     else if (gate == 1) DISPATCH(dtype, colreduce<T, RED_BNBWD_X><<<rgrid, red_threads(Cb), 0, s>>>(a));
     else DISPATCH(dtype, colreduce<T, RED_BNBWD_PLAIN><<<rgrid, red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
-    CVG_LAUNCH_CHECK();
+    if (a.fin == FIN_NONE) {
+        sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(a.ws, a.nblk, C, dbeta, dgamma, 1, 1, 0);
+        CVG_LAUNCH_CHECK();
+    }
     const int RL = 256 / (Cb / 8);
     int nb = ceil_div(M, (int64_t)RL * 4);
     if (nb > 4096) nb = 4096;
@@ -1263,10 +1409,14 @@ int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, f
     hipStream_t s = (hipStream_t)stream;
     const int Cb = col_block(C);
     RedArgs a = {x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, nullptr, M, C, ld, red_blocks(M, Cb), Cb};
+    if (red_finalize_setup(a, ws, FIN_SUMS, "colsum")) return -1;
+    a.out0 = out; a.out1 = nullptr; a.md = md; a.ma = ma; a.mb = mb;
     DISPATCH(dtype, colreduce<T, RED_SUM><<<dim3(a.nblk, ceil_div(C, Cb)), red_threads(Cb), 0, s>>>(a));
     CVG_LAUNCH_CHECK();
-    sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(ws, a.nblk, C, out, nullptr, md, ma, mb);
-    CVG_LAUNCH_CHECK();
+    if (a.fin == FIN_NONE) {
+        sum_finalize<<<grid1(C, FIN_CH), 256, 0, s>>>(a.ws, a.nblk, C, out, nullptr, md, ma, mb);
+        CVG_LAUNCH_CHECK();
+    }
     return 0;
 }
 

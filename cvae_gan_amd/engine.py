@@ -27,7 +27,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import ConvDesc, WMap, PAD_ZERO, PAD_REFLECT, FORM_S2_TRANSPOSED, CONV_ALONE
+from ._lib import ConvDesc, WMap, PAD_ZERO, PAD_REFLECT, FORM_S2_TRANSPOSED, CONV_ALONE, WS_HEADER
 
 # Checkpoint key prefixes.  The reference saves self.En.module.state_dict() (models/cvae.py:234-235):
 # En.module is the `encoder` wrapper, whose one child attribute is `self.encoder` (the inner
@@ -596,7 +596,9 @@ class Engine:
         max_c = max(self.ngf * 8, 4 * self.z)
         if self.dec is not None:
             max_c = max(max_c, self.dec["nout"], self.dec["F8"])
-        self.red_ws = torch.zeros(2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
+        # reduction workspaces start with WS_HEADER arrival counters (zero here, left at zero by every kernel that
+        # counts in them); kernels that only need scratch rows get the part behind them (red_rows)
+        self.red_ws = torch.zeros(WS_HEADER + 2 * 1024 * max(max_c, 1024), dtype=torch.float32, device=self.device)
         # the weight-gradient branches of backward run on side streams with workspaces of their own
         self._ws_sides = [torch.zeros(max(wg, 1 << 20) // 4 + 16, dtype=torch.float32, device=self.device)
                           for _ in range(self._n_side)]
@@ -633,7 +635,7 @@ class Engine:
         """partial_rows > 0: self.red_ws already holds that many rows of column sums / sums of squares of x
         (left there by the convolution that produced x)."""
         if self.training and partial_rows:
-            ops.bn_stats_finalize(self.red_ws, partial_rows, M, C, stats, self.buffers[prefix + ".running_mean"],
+            ops.bn_stats_finalize(self.red_rows, partial_rows, M, C, stats, self.buffers[prefix + ".running_mean"],
                                   self.buffers[prefix + ".running_var"], self.buffers[prefix + ".num_batches_tracked"])
         elif self.training:
             ops.bn_stats(x, M, C, stats, self.buffers[prefix + ".running_mean"],
@@ -657,8 +659,8 @@ class Engine:
         if self.training and nblk:
             # opt-in (see _stat_tiles): the convolution's epilogue leaves per-tile column sums of what it
             # stores, so the statistics need no pass over conv_out
-            assert 2 * nblk * C <= self.red_ws.numel()
-            self._fwd(g, x, conv_out, bias=bias, stat_partials=self.red_ws, **kw)
+            assert 2 * nblk * C <= self.red_rows.numel()
+            self._fwd(g, x, conv_out, bias=bias, stat_partials=self.red_rows, **kw)
             self._bn(conv_out, res, y, M, C, stats, prefix, partial_rows=nblk)
             return
         self._fwd(g, x, conv_out, bias=bias, **kw)
@@ -730,6 +732,10 @@ class Engine:
     @property
     def red_ws_side(self):
         return self._red_ws_sides[self._side_i]
+
+    @property
+    def red_rows(self):
+        return self.red_ws[WS_HEADER:]
 
     def _join(self):
         if self._side_dirty:
@@ -869,7 +875,7 @@ class Engine:
             self._wgrad(e["stem"], e["xpad"], e["d_s0"], ngf)
             if not frozen:
                 ops.label_bias_bwd(e["d_s0"], e["labels"], B, P * P, ngf, self.y, self.grads[EP + "conv.1.weight"],
-                                   self.grads[EP + "conv.1.bias"], self.red_ws_side)
+                                   self.grads[EP + "conv.1.bias"], self.red_ws_side[WS_HEADER:])
         d_img = None
         if input_grad:
             self._fwd(e["stem_dg"], e["d_s0"], e["d_xp"])
@@ -995,7 +1001,7 @@ class Engine:
         h = self.enc_forward(x, labels)
         zin = self.sample(h, eps, batch_size)
         dec = self.dec_forward(zin, d["mask"])
-        ops.mse_fwd_bwd(dec, x, d["d_dec"], self.losses[1:2], dec.numel(), batch_size, loss_scale, self.red_ws)
+        ops.mse_fwd_bwd(dec, x, d["d_dec"], self.losses[1:2], dec.numel(), batch_size, loss_scale, self.red_rows)
         dzin = self.dec_backward(d["d_dec"], d["mask"])
         self.sample_backward(dzin, eps, None, None, loss_scale, batch_size)
         return dec

@@ -135,7 +135,7 @@ class CVAEGAN:
         dimg_c = C.backward_generator()
         # ---- generator / encoder backward
         d = A.dec
-        ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, ls, A.red_ws)
+        ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, ls, A.red_rows)
         ops.axpy(d["d_dec"], dimg_d[B:2 * B], 1.0)
         ops.axpy(d["d_dec"], dimg_c[B:2 * B], 1.0)
         G2.dec["d_dec"].copy_(dimg_d[2 * B:])

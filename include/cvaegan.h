@@ -30,6 +30,7 @@ enum { CVG_F32 = 0, CVG_BF16 = 1 };
 enum { CVG_PAD_ZERO = 0, CVG_PAD_REFLECT = 1 };
 enum { CVG_FORM_GATHER = 0, CVG_FORM_S2_TRANSPOSED = 1 };
 enum { CVG_CONV_ALONE = 1 };
+enum { CVG_WS_HEADER = 40960 };      /* floats at the start of a reduction workspace: arrival counters, see cvg_bn_stats */
 
 int         cvg_version(void);
 const char* cvg_last_error(void);
@@ -203,10 +204,16 @@ int cvg_pack_image(const float* x, void* xpad, int32_t B, int32_t P, int32_t dty
  * mode, networks.py:174, :235, :238, :188).  Writes stats = {mean[C], invstd[C]} and,
  * if running_mean != NULL, updates running_mean / running_var (momentum 0.1,
  * unbiased variance) and increments *num_batches_tracked (int64).
- * ws: f32 [2][nblk][C] partials with nblk = cvg_bn_stats_blocks(M, C).
+ * ws: f32 workspace of 2 * cvg_bn_stats_blocks(M, C) * C floats, 8-byte aligned: CVG_WS_HEADER arrival counters,
+ * then the block partials and the partials of groups of 16 blocks.  The totals are formed in the same launch: the
+ * last block of a group to arrive sums the group, the last group sums the groups, each in index order, so the
+ * result does not depend on the arrival order.  The counters must be ZERO before the first call that uses a
+ * workspace (fill it with zeros once); every call leaves them at zero, so one workspace serves any sequence of
+ * calls of cvg_bn_stats / cvg_bn_act_bwd / cvg_colsum on one stream, whatever their shapes.  Calls that may overlap
+ * (different streams) need workspaces of their own.
  * The sums are taken about row 0 (sum of (x - x0), sum of (x - x0)^2), so the variance does
- * not lose digits when |mean| >> std or M is a handful of rows; between the two kernels of the
- * call the invstd half of `stats` holds x0.                                         */
+ * not lose digits when |mean| >> std or M is a handful of rows; during the call the invstd half of
+ * `stats` holds x0.                                                                  */
 int32_t cvg_bn_stats_blocks(int32_t M, int32_t C);
 int cvg_bn_stats(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
                  float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -226,11 +233,12 @@ int cvg_bn_stats_finalize(const float* partials, int32_t nblk, int32_t M, int32_
 /* cvg_bn_stats for callers that cannot allocate or pass device scratch memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
  * reference.  Same kernels, arguments and results as cvg_bn_stats without `ws`: the block partials
- * go to a 4 MiB array that is part of the library's device image (one copy per GPU the library runs
+ * go to a 4.7 MiB array that is part of the library's device image (one copy per GPU the library runs
  * on, held until the process ends), so the call allocates nothing.  Limit: C <= 1024 (larger C is
  * rejected with an error, use cvg_bn_stats).  All calls on one GPU share that array: calls whose
  * kernels may overlap on the same GPU (different streams) race and must be ordered by the caller.
- * Nothing needs clearing between calls: every partial that is read was written by the same call.  */
+ * Nothing needs clearing between calls: every partial that is read was written by the same call, and the
+ * arrival counters start at zero in the library's image and are left at zero by every call.       */
 int cvg_bn_stats_static(const void* x, int32_t dtype, int32_t M, int32_t C, float* stats,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         cvg_stream s);
@@ -256,7 +264,7 @@ int cvg_conv_bn_act_fwd(const cvg_conv_desc* d, const void* x, const void* w, vo
 /* Backward of the same: g = dy * (y > 0 ? 1 : 0.2);
  * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
  * The residual branch's gradient is g itself; consumers recompute it from (dy, y)
- * through cvg_conv_fwd's res/gate arguments.  ws as for cvg_bn_stats.
+ * through cvg_conv_fwd's res/gate arguments.  ws as for cvg_bn_stats (counters included).
  * y may be NULL for a BatchNorm without a residual input: the sign of the activation is then
  * recomputed from x (gamma * xhat + beta, the expression cvg_bn_act_fwd evaluates), which
  * saves one of the three tensor reads of both passes; beta is only read in that case.
@@ -266,7 +274,7 @@ int cvg_bn_act_bwd(const void* dy, const void* y, const void* x, void* dx, int32
                    float* dgamma, float* dbeta, float* ws, cvg_stream s);
 
 /* Column sums of rows[M][ld] over the first C columns -> out[C] (bias gradients).
- * out_map_d/a/b: out index of column c = (c / d)*a + (c % d)*b.                   */
+ * out_map_d/a/b: out index of column c = (c / d)*a + (c % d)*b.  ws as for cvg_bn_stats(M, C). */
 int cvg_colsum(const void* x, int32_t dtype, int32_t M, int32_t C, int32_t ld, float* out,
                int32_t map_d, int32_t map_a, int32_t map_b, float* ws, cvg_stream s);
 
