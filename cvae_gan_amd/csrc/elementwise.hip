@@ -1025,6 +1025,83 @@ __global__ void __launch_bounds__(256) upsample_pad_bwd(const T* __restrict__ du
     store8<T>(dx + (((size_t)b * h + iy) * w + ix) * C + ch * 8, acc);
 }
 
+// ---- backward of the up-convolution at LOW resolution ------------------------------------------------------
+// y = conv3x3_valid(U), U = pad(upsample(x)) is linear in x with a spatial operator A that does not mix channels:
+// U[u] = sum_q A[u, q] x[q].  Therefore, with Z_t[q] = sum_p A[p + t, q] dY[p] (tap t = (ky, kx); p over the
+// output pixels):      dX[q] = sum_t W_t^T Z_t[q]        dW_t = sum_q Z_t[q] (x) x[q]
+// i.e. both gradients are plain GEMMs over the LOW-resolution pixels with K = 9 N: a quarter of the
+// multiplications of the same gradients taken at the up-sampled resolution, and neither the gradient of U nor
+// the transposed up-sampling pass exists.  This kernel builds Z [B][h][w][9][N] from dY [B][2h][2w][N].
+// Per axis, x[i] appears in the padded up-sampled positions 2i .. 2i + 3 (and in the mirror rows at the borders),
+// which the outputs p = u - k (k = 0..2) read: the rows 2i - 2 .. 2i + 3 of dY, with the coefficient of x[i] in U[p + k].
+__device__ __forceinline__ float up_coef(int u, int i, int h) {       // coefficient of x[i] in padded up-sampled index u
+    int i0, i1;
+    float w0, w1;
+    up_src(unpad_reflect1(u, 2 * h), h, i0, i1, w0, w1);
+    return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
+}
+// grid: x over (column, 8-channel chunk), y = row, z = image (of the low-resolution grid)
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ dy, T* __restrict__ z, int B, int h, int w,
+                                                         int N) {
+    const int NC = N / 8, H2 = 2 * h, W2 = 2 * w;
+    int bx, iy, b;
+    xcd_block(bx, iy, b);
+    const int t = bx * blockDim.x + threadIdx.x;
+    if (t >= w * NC) return;
+    const int ix = t / NC, ch = t - ix * NC;
+    float wy[6][3];
+    int ry[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int p = 2 * iy - 2 + r;
+        const bool ok = p >= 0 && p < H2;
+        ry[r] = ok ? p : 0;                        // rows outside the image: weight 0, any valid address
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wy[r][k] = ok ? up_coef(p + k, iy, h) : 0.f;
+    }
+    float acc[3][3][8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[a][c][j] = 0.f;
+    const T* base = dy + (size_t)b * H2 * W2 * N + ch * 8;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int px = 2 * ix - 2 + c;
+        const bool okx = px >= 0 && px < W2;
+        const int cx = okx ? px : 0;
+        float v[6][8];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) load8<T>(base + ((size_t)ry[r] * W2 + cx) * N, v[r]);
+        float col[3][8];                           // the column's contribution per kernel row
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) s += wy[r][k] * v[r][j];
+                col[k][j] = s;
+            }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float wxk = okx ? up_coef(px + kx, ix, w) : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][kx][j] += wxk * col[k][j];
+        }
+    }
+    T* out = z + (((size_t)b * h + iy) * w + ix) * (size_t)(9 * N) + ch * 8;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) store8<T>(out + (k * 3 + kx) * N, acc[k][kx]);
+}
+
 // transpose of ReflectionPad2d(pad)
 __device__ __forceinline__ int fold_list(int y, int H, int pad, int (&pos)[3]) {
     int n = 0;
@@ -1511,6 +1588,15 @@ int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int
     CVG_CHECK(h <= 65535 && B <= 65535, "upsample_pad_bwd: grid too large");
     const dim3 grid(grid1((int64_t)w * (C / 8)), h, B);
     DISPATCH(dtype, upsample_pad_bwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)du, (T*)dx, B, h, w, C));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_upsample_taps_bwd(const void* dy, void* z, int32_t dtype, int32_t B, int32_t h, int32_t w, int32_t N,
+                          cvg_stream stream) {
+    CVG_CHECK(dy && z && B > 0 && h > 0 && w > 0 && N > 0 && N % 8 == 0, "upsample_taps_bwd: bad args");
+    CVG_CHECK(h <= 65535 && B <= 65535, "upsample_taps_bwd: grid too large");
+    const dim3 grid(grid1((int64_t)w * (N / 8)), h, B);
+    DISPATCH(dtype, upsample_taps_bwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (T*)z, B, h, w, N));
     CVG_LAUNCH_CHECK();
     return 0;
 }

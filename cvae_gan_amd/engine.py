@@ -266,6 +266,7 @@ class Engine:
         # the forward pass runs on one stream with nothing beside it (the weight-gradient side streams only exist
         # in backward): its convolutions may keep their workgroups resident (see CVG_CONV_ALONE)
         self._fwd_flags = CONV_ALONE if os.environ.get("CVG_NO_FWD_WALK") is None else 0
+        self.lowres_up_bwd = os.environ.get("CVG_UP_BWD_HIRES") is None      # A/B: gradients of the up-convolutions on the up-sampled grid
         self._side, self._side_dirty = None, False
         self._wgrad_descs = []          # weight-gradient-only descriptors (workspace sizing)
         self._pack_batch = None
@@ -524,12 +525,28 @@ class Engine:
                               _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key + "weight")
             up["fwd"].desc.flags = self._fwd_flags
             # dU = full correlation of dY with the flipped kernel (zero padding 2)
-            up["dg"] = _Gemm(self, _desc(T, B, 2 * h, 2 * h, cout, U, U, cin, 3, 9, off=(-2, -2)),
-                             _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key + "weight")
+            if not self.lowres_up_bwd:
+                up["dg"] = _Gemm(self, _desc(T, B, 2 * h, 2 * h, cout, U, U, cin, 3, 9, off=(-2, -2)),
+                                 _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key + "weight")
             up["u"] = self._t(B * U * U, cin)
-            up["d_u"] = self._t(B * U * U, cin)
             up["y"] = self._t(B * 4 * h * h, cout)
             up["d_y"] = self._t(B * 4 * h * h, cout)
+            if self.lowres_up_bwd:
+                # Backward at LOW resolution (see cvg_upsample_taps_bwd): z holds, per input pixel, the nine
+                # tap-shifted transposed up-samplings of d_y; the input gradient is then a one-tap GEMM
+                # d_x = z . W' with K = 9 cout, the weight gradient dW' = z^T x, both over B h h rows instead of
+                # B (2h + 2)^2 / B (2h)^2 rows with the same K: a quarter of the multiplications, and neither
+                # d_u nor the transposed up-sampling pass.
+                up["z"] = self._t(B * h * h, 9 * cout)
+                up["dg_low"] = _Gemm(self, _desc(T, B, h, h, 9 * cout, h, h, cin, 1, 1),
+                                     _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9), key + "weight")
+                up["wg_low_desc"] = _desc(T, B, h, h, cin, h, h, 9 * cout, 1, 1)
+                up["wg_low_map"] = _wmap(cout, 1, cin * 9, cin, 0, 9, 9 * cout, cin, 1)
+                self._wgrad_descs.append(up["wg_low_desc"])
+                d["ups"].append(up)
+                h *= 2
+                continue
+            up["d_u"] = self._t(B * U * U, cin)
             d["ups"].append(up)
             h *= 2
         key = DP + "conv.%d." % (self.n_stage + 1)
@@ -704,6 +721,13 @@ class Engine:
         if self._frozen:
             return
         ops.conv_wgrad(g.desc, x, dy, dy_ld, g.wmap, self.grads[g.key], self.ws_side)
+
+    def _wgrad_low(self, up, x_in):
+        """Weight gradient of an up-convolution from the low-resolution input and z (see _build_decoder)."""
+        if self._frozen:
+            return
+        ops.conv_wgrad(up["wg_low_desc"], x_in, up["z"], 9 * up["cout"], up["wg_low_map"],
+                       self.grads[up["key"] + "weight"], self.ws_side)
 
     @contextlib.contextmanager
     def _branch(self):
@@ -946,11 +970,20 @@ class Engine:
         for i in range(len(d["ups"]) - 1, -1, -1):
             up = d["ups"][i]
             M = B * 4 * up["h"] * up["h"]
+            d_x = d["d_x0"] if i == 0 else d["ups"][i - 1]["d_y"]
+            if self.lowres_up_bwd:
+                x_in = d["x0"] if i == 0 else d["ups"][i - 1]["y"]
+                with self._branch():
+                    ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws_side)
+                ops.upsample_taps_bwd(up["d_y"], up["z"], B, up["h"], up["h"], up["cout"])
+                with self._branch():
+                    self._wgrad_low(up, x_in)
+                self._fwd(up["dg_low"], up["z"], d_x)
+                continue
             with self._branch():
                 self._wgrad(up["fwd"], up["u"], up["d_y"], up["cout"])
                 ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws_side)
             self._fwd(up["dg"], up["d_y"], up["d_u"])
-            d_x = d["d_x0"] if i == 0 else d["ups"][i - 1]["d_y"]
             ops.upsample_pad_bwd(up["d_u"], d_x, B, up["h"], up["h"], up["cin"])
         with self._branch():
             self._wgrad(d["fc3"], d["g1"], d["d_x0"], d["nout"])

@@ -210,6 +210,11 @@ def upsample_pad_bwd(du, dx, B, h, w, C_):
     check(lib.cvg_upsample_pad_bwd(ptr(du), ptr(dx), dt(du), B, h, w, C_, stream()))
 
 
+def upsample_taps_bwd(dy, z, B, h, w, N):
+    """z [B][h][w][9][N] = the nine tap-shifted transposed up-samplings of dy [B][2h][2w][N]."""
+    check(lib.cvg_upsample_taps_bwd(ptr(dy), ptr(z), dt(dy), B, h, w, N, stream()))
+
+
 def reflect_fold(dxp, dx, B, H, W, C_, pad):
     check(lib.cvg_reflect_fold(ptr(dxp), ptr(dx), dt(dxp), B, H, W, C_, pad, stream()))
 

@@ -328,6 +328,17 @@ int cvg_upsample_pad_fwd(const void* x, void* u, int32_t dtype, int32_t B, int32
 int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int32_t h, int32_t w,
                          int32_t C, cvg_stream s);
 
+/* Backward of deconv3x3 (Interpolate x2 + ReflectionPad2d(1) + Conv2d 3x3, networks.py:274-281) at LOW
+ * resolution.  The up-sampling and padding are one linear spatial operator A (U[u] = sum_q A[u, q] x[q]) that does
+ * not mix channels, so with Z_t[q] = sum_p A[p + t, q] dY[p] for the nine kernel taps t:
+ *     dX[q] = sum_t W_t^T Z_t[q]          dW_t = sum_q Z_t[q] (x) x[q]
+ * two plain GEMMs over the low-resolution pixels with K = 9 N (cvg_conv_fwd / cvg_conv_wgrad with one-tap
+ * descriptors): a quarter of the multiplications of the same gradients taken on the up-sampled grid, and no
+ * gradient of the up-sampled tensor.  This call builds z [B][h][w][9][N] (dtype, tap = ky * 3 + kx) from
+ * dy [B][2h][2w][N]; N a multiple of 8.                                                                      */
+int cvg_upsample_taps_bwd(const void* dy, void* z, int32_t dtype, int32_t B, int32_t h, int32_t w,
+                          int32_t N, cvg_stream s);
+
 /* Transpose of ReflectionPad2d(pad): dxp [B][H+2p][W+2p][C] -> dx [B][H][W][C].     */
 int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_t H, int32_t W,
                      int32_t C, int32_t pad, cvg_stream s);

@@ -227,6 +227,40 @@ def test_s2_input_gradient_rejects_unsupported():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,h,cin,cout", [(3, 5, 16, 24), (2, 8, 64, 32), (5, 1, 32, 8), (2, 2, 8, 16), (1, 16, 128, 64)])
+def test_upconv_backward_at_low_resolution(dtype, B, h, cin, cout):
+    """deconv3x3 (bilinear x2, ReflectionPad2d(1), 3x3 conv; networks.py:274-281): input and weight gradient through
+    cvg_upsample_taps_bwd and two one-tap GEMMs over the low-resolution pixels, against autograd of the up-sampled
+    form; 1 x 1 and 2 x 2 inputs exercise the edge clamp and the mirror rows together."""
+    ops, _desc, _wmap = _mods()
+    g = torch.Generator().manual_seed(B * 100 + h * 10 + cin)
+    x = torch.randn(B, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    dy = torch.randn(B, cout, 2 * h, 2 * h, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, dy = x.bfloat16().float(), w.bfloat16().float(), dy.bfloat16().float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    u = F.pad(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), (1, 1, 1, 1), mode="reflect")
+    F.conv2d(u, w).backward(dy)
+    dyr = to_rows(dy, dtype)
+    z = torch.full((B * h * h, 9 * cout), 7.0, dtype=dtype, device="cuda")
+    ops.upsample_taps_bwd(dyr, z, B, h, h, cout)
+    dd = _desc(dtype, B, h, h, 9 * cout, h, h, cin, 1, 1)
+    dm = _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9)
+    dxr = torch.zeros(B * h * h, cin, dtype=dtype, device="cuda")
+    ops.conv_fwd(dd, z, pack(ops, dm, w.detach(), dd, dtype), dxr, ws=ws_for(ops, dd))
+    wd = _desc(dtype, B, h, h, cin, h, h, 9 * cout, 1, 1)
+    wm = _wmap(cout, 1, cin * 9, cin, 0, 9, 9 * cout, cin, 1)
+    gw = torch.full(w.shape, 7.0, device="cuda")
+    ops.conv_wgrad(wd, to_rows(x.detach(), dtype), z, 9 * cout, wm, gw, ws_for(ops, wd))
+    torch.cuda.synchronize()
+    tol = TOL[dtype] if dtype == torch.float32 else 3e-2        # bf16: z is rounded once more than the up-sampled form
+    assert relmax(from_rows(dxr, B, h, h, cin), x.grad) < tol
+    assert relmax(gw.cpu(), w.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_reflect_7x7_to3(dtype):
     """Decoder tail: ReflectionPad2d(3) + Conv2d(C, 3, 7) with 3 of 4 stored channels valid."""
     ops, _desc, _wmap = _mods()
