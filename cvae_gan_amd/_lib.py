@@ -92,6 +92,7 @@ def _load():
         "cvg_dropout_mask": (C.c_int, [vp, i64, C.c_uint64, vp]),
         "cvg_upsample_pad_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "cvg_upsample_pad_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+        "cvg_upsample_taps_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "cvg_upsample_taps_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "cvg_reflect_fold": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "cvg_image_u8_to_f32": (C.c_int, [vp, vp, i32, i32, vp]),

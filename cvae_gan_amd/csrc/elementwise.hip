@@ -1040,16 +1040,21 @@ __device__ __forceinline__ float up_coef(int u, int i, int h) {       // coeffic
     up_src(unpad_reflect1(u, 2 * h), h, i0, i1, w0, w1);
     return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
 }
-// grid: x over (column, 8-channel chunk), y = row, z = image (of the low-resolution grid)
+// A workgroup takes IXB consecutive positions of one low-resolution row and NCB 8-channel chunks (IXB * NCB = 256).
+// Pass 1 combines, per column of dY the row segment touches and per kernel row, the six rows of dY (one thread per
+// (column, chunk): six loads); the combinations meet in LDS; pass 2 combines six columns per position and kernel
+// column.  Each dY element is loaded about 1.1 times per kernel instead of nine.
+// grid: x over (row segment, chunk group), y = row, z = image (of the low-resolution grid)
 template <typename T>
 __global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ dy, T* __restrict__ z, int B, int h, int w,
-                                                         int N) {
+                                                         int N, int NCB) {
+    extern __shared__ __attribute__((aligned(16))) float colsum[];       // [3][2 IXB + 4][NCB][8]
     const int NC = N / 8, H2 = 2 * h, W2 = 2 * w;
+    const int IXB = 256 / NCB, NCOL = 2 * IXB + 4, ngrp = NC / NCB;
     int bx, iy, b;
     xcd_block(bx, iy, b);
-    const int t = bx * blockDim.x + threadIdx.x;
-    if (t >= w * NC) return;
-    const int ix = t / NC, ch = t - ix * NC;
+    const int seg = bx / ngrp, cg = bx - seg * ngrp;
+    const int ix0 = seg * IXB, ch0 = cg * NCB;
     float wy[6][3];
     int ry[6];
 #pragma unroll
@@ -1060,6 +1065,36 @@ __global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ d
 #pragma unroll
         for (int k = 0; k < 3; ++k) wy[r][k] = ok ? up_coef(p + k, iy, h) : 0.f;
     }
+    const T* base = dy + (size_t)b * H2 * W2 * N;
+    for (int idx = threadIdx.x; idx < NCOL * NCB; idx += 256) {
+        const int col = idx / NCB, chn = idx - col * NCB;
+        const int px = 2 * ix0 - 2 + col;
+        float s[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
+        if (px >= 0 && px < W2) {
+            float v[6][8];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) load8<T>(base + ((size_t)ry[r] * W2 + px) * N + (ch0 + chn) * 8, v[r]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[k][j] += wy[r][k] * v[r][j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float* dst = colsum + ((size_t)(k * NCOL + col) * NCB + chn) * 8;
+            *(f32x4*)dst = f32x4{s[k][0], s[k][1], s[k][2], s[k][3]};
+            *(f32x4*)(dst + 4) = f32x4{s[k][4], s[k][5], s[k][6], s[k][7]};
+        }
+    }
+    __syncthreads();
+    const int ixl = threadIdx.x / NCB, chn = threadIdx.x - ixl * NCB, ix = ix0 + ixl;
+    if (ix >= w) return;
     float acc[3][3][8];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -1067,39 +1102,97 @@ __global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ d
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[a][c][j] = 0.f;
-    const T* base = dy + (size_t)b * H2 * W2 * N + ch * 8;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const int px = 2 * ix - 2 + c;
         const bool okx = px >= 0 && px < W2;
-        const int cx = okx ? px : 0;
-        float v[6][8];
+        float wxk[3];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) load8<T>(base + ((size_t)ry[r] * W2 + cx) * N, v[r]);
-        float col[3][8];                           // the column's contribution per kernel row
+        for (int kx = 0; kx < 3; ++kx) wxk[kx] = okx ? up_coef(px + kx, ix, w) : 0.f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k) {
+            const float* src = colsum + ((size_t)(k * NCOL + 2 * ixl + c) * NCB + chn) * 8;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float s = 0.f;
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int r = 0; r < 6; ++r) s += wy[r][k] * v[r][j];
-                col[k][j] = s;
-            }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float wxk = okx ? up_coef(px + kx, ix, w) : 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[k][kx][j] += wxk * col[k][j];
+                for (int j = 0; j < 4; ++j) {
+                    acc[k][kx][j] += wxk[kx] * lo[j];
+                    acc[k][kx][4 + j] += wxk[kx] * hi[j];
+                }
         }
     }
-    T* out = z + (((size_t)b * h + iy) * w + ix) * (size_t)(9 * N) + ch * 8;
+    T* out = z + (((size_t)b * h + iy) * w + ix) * (size_t)(9 * N) + (ch0 + chn) * 8;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) store8<T>(out + (k * 3 + kx) * N, acc[k][kx]);
+}
+
+// ---- forward of the up-convolution at LOW resolution --------------------------------------------------------
+// By the same linearity, y[p] = bias + sum_t sum_q A[p + t, q] V_t[q] with V_t[q] = W_t x[q]: the channel mixing is
+// ONE GEMM over the low-resolution pixels with 9 N output columns (a quarter of the multiplications of the
+// convolution over the up-sampled tensor, which never exists), and this kernel applies the spatial operator:
+// v [B][h][w][9][N] -> y [B][2h][2w][N].  A thread owns one low-resolution position and 8 channels, i.e. the 2 x 2
+// output pixels 2a + {0, 1}, 2b + {0, 1}; they read taps of the 3 x 3 positions around (a, b) only.
+// grid: x over (column, 8-channel chunk), y = row, z = image (of the low-resolution grid)
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_taps_fwd(const T* __restrict__ v, const float* __restrict__ bias,
+                                                         T* __restrict__ y, int B, int h, int w, int N) {
+    const int NC = N / 8;
+    int bx, a, b;
+    xcd_block(bx, a, b);
+    const int t = bx * blockDim.x + threadIdx.x;
+    if (t >= w * NC) return;
+    const int ix = t / NC, ch = t - ix * NC;
+    // coefficient of x[a - 1 + d] in the padded up-sampled row that output row 2a + par reads at kernel row k
+    float wy[2][3][3], wx[2][3][3];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int qy = a - 1 + d, qx = ix - 1 + d;
+                wy[par][k][d] = (qy >= 0 && qy < h) ? up_coef(2 * a + par + k, qy, h) : 0.f;
+                wx[par][k][d] = (qx >= 0 && qx < w) ? up_coef(2 * ix + par + k, qx, w) : 0.f;
+            }
+    float acc[2][2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float bv = bias ? bias[ch * 8 + j] : 0.f;
+        acc[0][0][j] = acc[0][1][j] = acc[1][0][j] = acc[1][1][j] = bv;
+    }
+    const T* base = v + (size_t)b * h * w * (9 * N) + ch * 8;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int qy = min(max(a - 1 + dy, 0), h - 1);         // positions outside the image: weight 0, any valid address
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int qx = min(max(ix - 1 + dx, 0), w - 1);
+            const T* src = base + ((size_t)qy * w + qx) * (9 * N);
+            float val[9][8];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) load8<T>(src + tp * N, val[tp]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int py = 0; py < 2; ++py)
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            const float c = wy[py][ky][dy] * wx[px][kx][dx];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[py][px][j] += c * val[ky * 3 + kx][j];
+                        }
+        }
+    }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+            store8<T>(y + (((size_t)b * 2 * h + 2 * a + py) * (2 * w) + 2 * ix + px) * N + ch * 8, acc[py][px]);
 }
 
 // transpose of ReflectionPad2d(pad)
@@ -1591,12 +1684,27 @@ int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int
     CVG_LAUNCH_CHECK();
     return 0;
 }
+int cvg_upsample_taps_fwd(const void* v, const float* bias, void* y, int32_t dtype, int32_t B, int32_t h, int32_t w,
+                          int32_t N, cvg_stream stream) {
+    CVG_CHECK(v && y && B > 0 && h > 0 && w > 0 && N > 0 && N % 8 == 0, "upsample_taps_fwd: bad args");
+    CVG_CHECK(h <= 65535 && B <= 65535, "upsample_taps_fwd: grid too large");
+    const dim3 grid(grid1((int64_t)w * (N / 8)), h, B);
+    DISPATCH(dtype, upsample_taps_fwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)v, bias, (T*)y, B, h, w, N));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
 int cvg_upsample_taps_bwd(const void* dy, void* z, int32_t dtype, int32_t B, int32_t h, int32_t w, int32_t N,
                           cvg_stream stream) {
     CVG_CHECK(dy && z && B > 0 && h > 0 && w > 0 && N > 0 && N % 8 == 0, "upsample_taps_bwd: bad args");
     CVG_CHECK(h <= 65535 && B <= 65535, "upsample_taps_bwd: grid too large");
-    const dim3 grid(grid1((int64_t)w * (N / 8)), h, B);
-    DISPATCH(dtype, upsample_taps_bwd<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (T*)z, B, h, w, N));
+    // 8-channel chunks per workgroup: the largest power of two <= 32 that divides N / 8 (256 threads = positions x chunks)
+    int ncb = 1;
+    while (ncb < 32 && (N / 8) % (ncb * 2) == 0) ncb *= 2;
+    const int ixb = 256 / ncb;
+    const size_t lds = (size_t)3 * (2 * ixb + 4) * ncb * 8 * sizeof(float);
+    CVG_CHECK(lds <= 64 * 1024, "upsample_taps_bwd: internal: %zu bytes of LDS", lds);
+    const dim3 grid(ceil_div(w, ixb) * ((N / 8) / ncb), h, B);
+    DISPATCH(dtype, upsample_taps_bwd<T><<<grid, 256, lds, (hipStream_t)stream>>>((const T*)dy, (T*)z, B, h, w, N, ncb));
     CVG_LAUNCH_CHECK();
     return 0;
 }

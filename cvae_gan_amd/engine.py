@@ -267,6 +267,11 @@ class Engine:
         # in backward): its convolutions may keep their workgroups resident (see CVG_CONV_ALONE)
         self._fwd_flags = CONV_ALONE if os.environ.get("CVG_NO_FWD_WALK") is None else 0
         self.lowres_up_bwd = os.environ.get("CVG_UP_BWD_HIRES") is None      # A/B: gradients of the up-convolutions on the up-sampled grid
+        # The forward pass the same way (one-tap GEMM with 9 cout columns, then the spatial operator) does a quarter
+        # of the multiplications too, but moves as many bytes as the convolution over the up-sampled tensor (v is as
+        # large as u), and that convolution runs at 1 PFLOP/s: measured 0.16 ms per step SLOWER with the present
+        # one-tap GEMM and operator kernels.  Opt-in.
+        self.lowres_up_fwd = os.environ.get("CVG_UP_FWD_LOWRES") is not None
         self._side, self._side_dirty = None, False
         self._wgrad_descs = []          # weight-gradient-only descriptors (workspace sizing)
         self._pack_batch = None
@@ -521,16 +526,24 @@ class Engine:
             U = 2 * h + 2
             up = {"key": key, "h": h, "cin": cin, "cout": cout}
             # valid 3x3 conv on the up-sampled, reflection-padded tensor U
-            up["fwd"] = _Gemm(self, _desc(T, B, U, U, cin, 2 * h, 2 * h, cout, 3, 9),
-                              _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key + "weight")
-            up["fwd"].desc.flags = self._fwd_flags
+            if not (self.lowres_up_fwd and self.lowres_up_bwd):
+                up["fwd"] = _Gemm(self, _desc(T, B, U, U, cin, 2 * h, 2 * h, cout, 3, 9),
+                                  _wmap(1, cin * 9, 0, cin, 1, 9, cout, cin, 9), key + "weight")
+                up["fwd"].desc.flags = self._fwd_flags
             # dU = full correlation of dY with the flipped kernel (zero padding 2)
             if not self.lowres_up_bwd:
                 up["dg"] = _Gemm(self, _desc(T, B, 2 * h, 2 * h, cout, U, U, cin, 3, 9, off=(-2, -2)),
                                  _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9, tap_mode=1), key + "weight")
-            up["u"] = self._t(B * U * U, cin)
+            if not (self.lowres_up_fwd and self.lowres_up_bwd):
+                up["u"] = self._t(B * U * U, cin)
             up["y"] = self._t(B * 4 * h * h, cout)
             up["d_y"] = self._t(B * 4 * h * h, cout)
+            if self.lowres_up_fwd:
+                # Forward at LOW resolution (see cvg_upsample_taps_fwd): v = x . W' with 9 cout columns, then the
+                # spatial operator; the up-sampled tensor is never built
+                up["v"] = self._t(B * h * h, 9 * cout)
+                up["v_gemm"] = _Gemm(self, _desc(T, B, h, h, cin, h, h, 9 * cout, 1, 1),
+                                     _wmap(cout, 1, cin * 9, cin, 0, 9, 9 * cout, cin, 1), key + "weight")
             if self.lowres_up_bwd:
                 # Backward at LOW resolution (see cvg_upsample_taps_bwd): z holds, per input pixel, the nine
                 # tap-shifted transposed up-samplings of d_y; the input gradient is then a one-tap GEMM
@@ -942,8 +955,14 @@ class Engine:
         self._fwd(d["fc3"], d["g1"], d["x0"], bias=d["bias3"])
         x = d["x0"]
         for up in d["ups"]:
-            ops.upsample_pad_fwd(x, up["u"], B, up["h"], up["h"], up["cin"])
-            self._fwd(up["fwd"], up["u"], up["y"], bias=self.params[up["key"] + "bias"])
+            if self.lowres_up_fwd:
+                self._fwd(up["v_gemm"], x, up["v"])
+                ops.upsample_taps_fwd(up["v"], self.params[up["key"] + "bias"], up["y"], B, up["h"], up["h"], up["cout"])
+                if self.training and not self.lowres_up_bwd:        # (A/B) the weight gradient on the up-sampled grid reads u
+                    ops.upsample_pad_fwd(x, up["u"], B, up["h"], up["h"], up["cin"])
+            else:
+                ops.upsample_pad_fwd(x, up["u"], B, up["h"], up["h"], up["cin"])
+                self._fwd(up["fwd"], up["u"], up["y"], bias=self.params[up["key"] + "bias"])
             x = up["y"]
         if d["tail_v"] is not None:
             self._fwd(d["tail_v"], x, d["v"])

@@ -210,6 +210,11 @@ def upsample_pad_bwd(du, dx, B, h, w, C_):
     check(lib.cvg_upsample_pad_bwd(ptr(du), ptr(dx), dt(du), B, h, w, C_, stream()))
 
 
+def upsample_taps_fwd(v, bias, y, B, h, w, N):
+    """y [B][2h][2w][N] = bias + the up-sampling / padding / tap-shift operator applied to v [B][h][w][9][N]."""
+    check(lib.cvg_upsample_taps_fwd(ptr(v), ptr(bias), ptr(y), dt(v), B, h, w, N, stream()))
+
+
 def upsample_taps_bwd(dy, z, B, h, w, N):
     """z [B][h][w][9][N] = the nine tap-shifted transposed up-samplings of dy [B][2h][2w][N]."""
     check(lib.cvg_upsample_taps_bwd(ptr(dy), ptr(z), dt(dy), B, h, w, N, stream()))

@@ -338,6 +338,12 @@ int cvg_upsample_pad_bwd(const void* du, void* dx, int32_t dtype, int32_t B, int
  * dy [B][2h][2w][N]; N a multiple of 8.                                                                      */
 int cvg_upsample_taps_bwd(const void* dy, void* z, int32_t dtype, int32_t B, int32_t h, int32_t w,
                           int32_t N, cvg_stream s);
+/* ... and its forward the same way: y[p] = bias + sum_t sum_q A[p + t, q] V_t[q] with V_t[q] = W_t x[q].  The
+ * channel mixing is ONE one-tap GEMM over the low-resolution pixels with 9 N output columns (cvg_conv_fwd; a
+ * quarter of the multiplications of the convolution over the up-sampled tensor, which is never built); this call
+ * applies the spatial operator: v [B][h][w][9][N] -> y [B][2h][2w][N] (dtype), bias f32 [N] or NULL.          */
+int cvg_upsample_taps_fwd(const void* v, const float* bias, void* y, int32_t dtype, int32_t B, int32_t h,
+                          int32_t w, int32_t N, cvg_stream s);
 
 /* Transpose of ReflectionPad2d(pad): dxp [B][H+2p][W+2p][C] -> dx [B][H][W][C].     */
 int cvg_reflect_fold(const void* dxp, void* dx, int32_t dtype, int32_t B, int32_t H, int32_t W,

@@ -258,6 +258,16 @@ def test_upconv_backward_at_low_resolution(dtype, B, h, cin, cout):
     tol = TOL[dtype] if dtype == torch.float32 else 3e-2        # bf16: z is rounded once more than the up-sampled form
     assert relmax(from_rows(dxr, B, h, h, cin), x.grad) < tol
     assert relmax(gw.cpu(), w.grad) < tol
+    # forward the same way: v = x . W' (9 cout columns), then the spatial operator and the bias
+    bias = torch.randn(cout, generator=g)
+    y_ref = F.conv2d(u, w, bias).detach()
+    vd = _desc(dtype, B, h, h, cin, h, h, 9 * cout, 1, 1)
+    v = torch.full((B * h * h, 9 * cout), 7.0, dtype=dtype, device="cuda")
+    ops.conv_fwd(vd, to_rows(x.detach(), dtype), pack(ops, wm, w.detach(), vd, dtype), v, ws=ws_for(ops, vd))
+    yr = torch.full((B * 4 * h * h, cout), 7.0, dtype=dtype, device="cuda")
+    ops.upsample_taps_fwd(v, bias.cuda(), yr, B, h, h, cout)
+    torch.cuda.synchronize()
+    assert relmax(from_rows(yr, B, 2 * h, 2 * h, cout), y_ref) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
