@@ -27,7 +27,12 @@ CONFIGS = {
     "c4": (128, 100, 32, 64, 4),
     "c4d": (128, 100, 32, 64, 5),          # "deeper stacks": ndown = nup = 5 (networks.py:165, :133)
     "cli": (512, 1000, 256, 50, 4),        # the reference's command-line defaults (starter.py:19-27)
+    "c5": (128, 100, 32, 1024, 4),         # inference only: eval-mode encoder + sampler + decoder forward (cvae.py:197-220)
 }
+# forward multiply-adds per image of the reference's formulation with the label planes folded (the figure the
+# survey's roofline section quotes), for the "reference_formulation" entries of the JSON line: (forward GMAC, stem GMAC)
+REFERENCE_GMAC = {"c2": (0.652, 0.0096), "c3": (2.611, 0.0385), "c4": (10.447, 0.1541), "c4d": (10.921, 0.1541),
+                  "c5": (10.447, 0.1541)}
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
@@ -210,6 +215,89 @@ def cpu_baseline(P, y, z, n_stage=4, seconds_budget=14.0):
     return out
 
 
+def load_traffic(config, family):
+    """Memory-side bytes per launch of a kernel family from the newest counter file under profiles/ for this
+    configuration (tools/profile_round.sh writes profiles/<tag>_hbm_traffic_<config>.json), or None."""
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    paths = sorted(glob.glob(os.path.join(here, "*hbm_traffic_%s.json" % config)), key=os.path.getmtime)
+    for path in reversed(paths):
+        with open(path) as f:
+            got = json.load(f).get(family.replace("(+reduce)", ""), {}).get("bytes")
+        if got is not None:
+            return got
+    return None
+
+
+def infer_main(args, eng, batches, json_fd, P, y, z, B, n_stage, world):
+    """--config c5: eval-mode reconstruction (encoder + sampler + decoder forward, BatchNorm folded into the
+    convolution epilogues, no dropout) of `B` images per step, replayed from a HIP graph."""
+    assert world == 1, "the inference configuration runs on one GPU"
+    eng.training = False
+    x0, l0, e0 = batches[0]
+    gx, gl, ge = x0.clone(), l0.clone(), e0.clone()
+    for _ in range(max(args.warmup, 1)):
+        eng.reconstruct(gx, gl, ge)
+    torch.cuda.synchronize()
+    use_graph = not args.no_graph
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eng.reconstruct(gx, gl, ge)
+
+    def step(i):
+        x, labels, eps = batches[i % len(batches)]
+        gx.copy_(x)
+        gl.copy_(labels)
+        ge.copy_(eps)
+        if use_graph:
+            graph.replay()
+        else:
+            eng.reconstruct(gx, gl, ge)
+
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # roofline of the dominant kernel: event brackets around every GEMM launch of two eager passes
+    wa = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
+    wb = torch.empty_like(wa)
+    with KernelTimer(eng) as kt:
+        for i in range(2):
+            for _ in range(24):
+                torch.mm(wa, wa, out=wb)
+            eng.reconstruct(gx, gl, ge)
+        agg = kt.summary()
+        if args.per_layer:
+            print(kt.per_layer(2), file=sys.stderr)
+    name, (fl, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    executed = sum(v[0] for v in agg.values()) / 2
+    roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / t / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(fl / t / 1e12 / peak, 4), "traffic": load_traffic(args.config, name),
+                "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
+                "all_gemm_ms_per_step": round(sum(v[1] for v in agg.values()) / 2 * 1e3, 3),
+                "executed_tflop_per_step": round(executed / 1e12, 4),
+                "step_tflops_executed": round(executed / (dt / args.steps) / 1e12, 1),
+                "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3)}
+                               for k, v in sorted(agg.items())}}
+    out = {
+        "metric": "inference images/sec", "value": round(B * args.steps / dt, 1), "unit": "images/sec",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "CVAE inference (eval-mode encoder + sampler + decoder forward), %dx%dx3, %d classes, z_dim %d, "
+                               "%d down/up stages, batch %d, random-init weights" % (P, P, y, z, n_stage, B),
+                   "name": args.config, "global_batch": B, "parallelism": "dp1",
+                   "launch": "hip-graph" if use_graph else "eager"},
+        "roofline": roofline,
+    }
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +373,9 @@ def main():
     if multi:
         (dec_lo, dec_hi), (up_lo, up_hi) = eng.arena_range("dec"), eng.enc_upper_range()
         assert dec_lo == 0 and up_lo == dec_hi, "arena order: decoder, encoder head + deep blocks, the rest"
+
+    if args.config == "c5":
+        return infer_main(args, eng, batches, json_fd, P, y, z, B, n_stage, world)
 
     def step(i):
         x, labels, eps = batches[i % len(batches)]
@@ -419,15 +510,19 @@ def main():
     # HBM-side bytes per launch of that kernel family: PMC counters (FETCH_SIZE doubled as gfx950
     # needs, plus WRITE_SIZE) from two separate rocprofv3 passes over this same command, reduced by
     # tools/pmc_traffic.py into profiles/; null when the file is absent or lacks the family
-    traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_%s.json" % args.config)
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get(name.replace("(+reduce)", ""), {}).get("bytes")
+    traffic = load_traffic(args.config, name)
     roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
                 "all_gemm_ms_per_step": round(total_gemm_t * 1e3, 3),
+                # FLOPs the step's GEMM launches execute (the gradients of the up-convolutions are taken at low
+                # resolution: a quarter of the multiplications of the reference's formulation for those layers),
+                # and what the reference's own formulation of the step would take (forward GMAC g, stem s:
+                # 2 * (3 g - s) per image, label planes folded)
+                "executed_tflop_per_step": round(sum(v[0] for v in agg.values()) / 2 / 1e12, 4),
+                "step_tflops_executed": round(sum(v[0] for v in agg.values()) / 2 / (dt / args.steps) / 1e12, 1),
+                "reference_formulation_tflop_per_step": (round(2 * (3 * REFERENCE_GMAC[args.config][0] - REFERENCE_GMAC[args.config][1]) * B / 1e3, 4)
+                                                         if args.config in REFERENCE_GMAC else None),
                 "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3)}
                                for k, v in sorted(agg.items())},
                 # the step's HBM-bound passes: algorithmic bytes / event-bracketed time (small finalize

@@ -243,6 +243,14 @@ class _Gemm:
         ops.weight_pack(self.desc, self.wmap, eng.params[self.key], self.w)
 
 
+class _WgradOnly:
+    """A weight-gradient geometry without a packed-weight layout of its own."""
+
+    def __init__(self, eng, desc, wmap, canonical_key):
+        self.desc, self.wmap, self.key = desc, wmap, canonical_key
+        eng._wgrad_descs.append(desc)
+
+
 class Engine:
     def __init__(self, pix_dim, y_dim, z_dim, batch, dtype=torch.bfloat16, ngf=64, n_stage=4,
                  device="cuda", seed=0, state=None, share=None, parts="both", extra_params=None,
@@ -553,9 +561,8 @@ class Engine:
                 up["z"] = self._t(B * h * h, 9 * cout)
                 up["dg_low"] = _Gemm(self, _desc(T, B, h, h, 9 * cout, h, h, cin, 1, 1),
                                      _wmap(1, 9, 0, cout, 1, cin * 9, cin, cout, 9), key + "weight")
-                up["wg_low_desc"] = _desc(T, B, h, h, cin, h, h, 9 * cout, 1, 1)
-                up["wg_low_map"] = _wmap(cout, 1, cin * 9, cin, 0, 9, 9 * cout, cin, 1)
-                self._wgrad_descs.append(up["wg_low_desc"])
+                up["wg_low"] = _WgradOnly(self, _desc(T, B, h, h, cin, h, h, 9 * cout, 1, 1),
+                                          _wmap(cout, 1, cin * 9, cin, 0, 9, 9 * cout, cin, 1), key + "weight")
                 d["ups"].append(up)
                 h *= 2
                 continue
@@ -734,13 +741,6 @@ class Engine:
         if self._frozen:
             return
         ops.conv_wgrad(g.desc, x, dy, dy_ld, g.wmap, self.grads[g.key], self.ws_side)
-
-    def _wgrad_low(self, up, x_in):
-        """Weight gradient of an up-convolution from the low-resolution input and z (see _build_decoder)."""
-        if self._frozen:
-            return
-        ops.conv_wgrad(up["wg_low_desc"], x_in, up["z"], 9 * up["cout"], up["wg_low_map"],
-                       self.grads[up["key"] + "weight"], self.ws_side)
 
     @contextlib.contextmanager
     def _branch(self):
@@ -996,7 +996,7 @@ class Engine:
                     ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws_side)
                 ops.upsample_taps_bwd(up["d_y"], up["z"], B, up["h"], up["h"], up["cout"])
                 with self._branch():
-                    self._wgrad_low(up, x_in)
+                    self._wgrad(up["wg_low"], x_in, up["z"], 9 * up["cout"])
                 self._fwd(up["dg_low"], up["z"], d_x)
                 continue
             with self._branch():
