@@ -391,68 +391,20 @@ def main():
         note("step %d enqueued" % i)
         eng.adamw_step(args.lr)
 
-    # A HIP graph of one whole step removes the per-launch host cost (about 200 launches per step).
-    # With N > 1 the step is four graphs with the gradient exchanges between them: [forward +
-    # decoder backward] -> all-reduce of the decoder's range (on a side stream, overlapping the next
-    # graph) -> [encoder head + deep blocks backward] -> all-reduce of their range -> [shallow blocks
-    # + stem backward] -> all-reduce of the rest -> [AdamW].
+    # A HIP graph of one whole step removes the per-launch host cost (about 170 launches per step).  With
+    # N > 1 the step is four graphs with the gradient exchanges between them (cvae_gan_amd.ddp.GraphedStep, the
+    # schedule the multi-rank trainer runs as well).
     use_graph = not args.no_graph
     for i in range(max(args.warmup, 1)):
         step(i)
     torch.cuda.synchronize()
     note("eager warm-up done")
     if use_graph:
-        x0, l0, e0 = batches[0]
-        gx, gl, ge = x0.clone(), l0.clone(), e0.clone()
-        eng.grad_ready = None
-        eng.pack_weights(force=True)
-        saved = eng.step_count
-        if not multi:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                eng.random_mask()
-                eng._packed_version = -1
-                eng.forward_backward(gx, gl, ge, batch_size_flag, loss_scale)
-                eng.adamw_step(args.lr)
-
-            def run_graphs():
-                graph.replay()
-        else:
-            g_head, g_enc, g_enc2, g_opt = (torch.cuda.CUDAGraph() for _ in range(4))
-            pool = torch.cuda.graph_pool_handle()
-            # thread-local capture mode: the process group's watchdog thread polls events while this
-            # thread captures, which the default (global) mode would treat as a capture violation
-            tl = {"pool": pool, "capture_error_mode": "thread_local"}
-            with torch.cuda.graph(g_head, **tl):
-                eng.random_mask()
-                eng._packed_version = -1
-                eng.forward_backward_decoder(gx, gl, ge, batch_size_flag, loss_scale)
-            with torch.cuda.graph(g_enc, **tl):
-                eng.enc_backward(eng.enc["dh"], part="upper")
-            with torch.cuda.graph(g_enc2, **tl):
-                eng.enc_backward(eng.enc["dh"], part="lower")
-            with torch.cuda.graph(g_opt, **tl):
-                eng.adamw_step(args.lr)
-
-            def run_graphs():
-                sync.begin_step()
-                g_head.replay()
-                sync.group_ready(0)                          # the decoder's range
-                g_enc.replay()
-                sync.group_ready(1)                          # encoder head + deep blocks
-                g_enc2.replay()
-                sync.group_ready(2)                          # shallow blocks + stem
-                sync.finish()
-                g_opt.replay()
-            assert sync.groups[1][-1] == "enc.blk%d" % eng.enc_split, "graph boundaries follow the exchange groups"
-        eng.step_count = saved
+        gstep = ddp.GraphedStep(eng, batch_size_flag, args.lr, loss_scale, sync=sync if multi else None)
+        gstep.capture(*batches[0])
 
         def step(i):                                    # noqa: F811
-            x, labels, eps = batches[i % len(batches)]
-            gx.copy_(x)
-            gl.copy_(labels)
-            ge.copy_(eps)
-            run_graphs()
+            gstep.run(*batches[i % len(batches)])
 
         step(0)
         torch.cuda.synchronize()

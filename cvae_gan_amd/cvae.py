@@ -110,18 +110,18 @@ class CVAE(object):
                                  device=self.device, seed=seed)
         self._sample_engine = None
         self.sync = None
-        # one replica, plain CVAE: after two eager steps the whole step (dropout draw, forward, backward,
-        # AdamW, weight repack) is captured into a HIP graph and replayed on static input buffers
-        # (args.graph = False or CVG_TRAINER_EAGER: eager launches throughout)
-        self._use_graph = (self.world == 1 and self.gan is None and getattr(args, "graph", True)
+        # plain CVAE: after two eager steps the whole step (dropout draw, forward, backward, gradient exchange,
+        # AdamW, weight repack) is captured into HIP graphs and replayed on static input buffers: one graph on
+        # one replica, four with the exchanges between them on several (ddp.GraphedStep, the schedule bench.py
+        # times).  args.graph = False or CVG_TRAINER_EAGER: eager launches throughout.
+        self._use_graph = (self.gan is None and getattr(args, "graph", True)
                            and os.environ.get("CVG_TRAINER_EAGER") is None)
-        self._graph, self._graph_in, self._graph_out, self._steps_done = None, None, None, 0
+        self._graph, self._steps_done = None, 0
         if self.world > 1 and self.gan is not None:
             self.gan.broadcast_state()                            # the three arenas are summed after backward
         elif self.world > 1:
             ddp.broadcast_state(self.engine)                      # every replica starts from rank 0's state
             self.sync = ddp.GradSync.for_engine(self.engine)
-            self.engine.grad_ready = self.sync.on_ready
         self._eps_gen = torch.Generator(device=self.device).manual_seed(seed * 7919 + 17 + self.rank)
         if getattr(args, "resume", False):
             try:
@@ -189,36 +189,40 @@ class CVAE(object):
         global batch) divides both losses as in the reference (:137, :139); with N ranks every local
         loss is scaled by 1/N, so the summed gradients are those of the global-batch mean."""
         eng = self.engine
-        if self.sync is None:
-            self._steps_done += 1
-            if not self._use_graph or self._steps_done <= 2:
-                eng.random_mask()
-                return eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
-            return self._replay_step(x, cls, eps)
+        self._steps_done += 1
+        if self._use_graph and self._steps_done > 2:
+            got = self._replay_step(x, cls, eps)
+            if got is not None:
+                return got
         eng.random_mask()
+        if self.sync is None:
+            return eng.train_step(x, cls, eps, float(self.batch_size), self.lr)
         self.sync.begin_step()
-        dec = eng.forward_backward(x, cls, eps, float(self.batch_size), loss_scale=1.0 / self.world)
+        eng.grad_ready = self.sync.on_ready              # exchanges start as backward reports its stages
+        try:
+            dec = eng.forward_backward(x, cls, eps, float(self.batch_size), loss_scale=1.0 / self.world)
+        finally:
+            eng.grad_ready = None
         self.sync.finish()
         eng.adamw_step(self.lr)
         return dec
 
     def _replay_step(self, x, cls, eps):
-        eng = self.engine
+        """The step from HIP graphs; None (and eager launches from then on) if the capture fails, e.g. because
+        another thread of the process made a call that cannot be captured."""
         if self._graph is None:
-            self._graph_in = (torch.empty_like(x), torch.empty_like(cls), torch.empty_like(eps))
-            eng.pack_weights(force=True)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                eng._packed_version = -1             # the captured step repacks the weights it updated last time
-                eng.random_mask()
-                self._graph_out = eng.train_step(*self._graph_in, float(self.batch_size), self.lr)
-            self._graph = graph
-        for dst, src in zip(self._graph_in, (x, cls, eps)):
-            dst.copy_(src)
-        self._graph.replay()
-        eng.params_changed()                         # host-side version: engines that share the weights repack
-        return self._graph_out
+            step = ddp.GraphedStep(self.engine, self.batch_size, self.lr, 1.0 / self.world, sync=self.sync)
+            try:
+                step.capture(x, cls, eps)
+            except Exception as exc:                     # noqa: BLE001 (whatever the runtime raised: fall back, do not die)
+                torch.cuda.synchronize()
+                self._use_graph = False
+                self.engine._packed_version = -1
+                self._print("HIP-graph capture of the train step failed (%s: %s); continuing with eager launches"
+                            % (type(exc).__name__, exc))
+                return None
+            self._graph = step
+        return self._graph.run(x, cls, eps)
 
     def read_losses(self):
         """The losses of the whole (global) batch: the mean of the ranks' values."""

@@ -93,6 +93,7 @@ class GradSync:
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.cuda else None
         self._pending = None
         self._works = []
+        self._events = []
         self.launched = []          # (lo, hi) of every exchange of the current step, for tests
 
     @classmethod
@@ -106,8 +107,13 @@ class GradSync:
     def begin_step(self):
         assert self._pending is None and not self._works, "the previous step was not finished"
         self.launched = []
+        self._events = []
 
-    def on_ready(self, stage):
+    def on_ready(self, stage, events=()):
+        """events: HIP events recorded on other streams (the engine's weight-gradient side streams) that
+        the stage's gradients also wait for; the exchange waits for them on the communication stream, so
+        the compute stream that reports the stage never has to."""
+        self._events.extend(events)
         lo, hi = self.ranges[stage]
         if self._pending is None:
             self._pending = (lo, hi)
@@ -138,8 +144,11 @@ class GradSync:
             return
         ev = torch.cuda.Event()
         ev.record()                                   # gradients of this range are enqueued up to here
+        events, self._events = self._events, []
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
+            for e in events:                          # ... and on the side streams up to these
+                self.comm_stream.wait_event(e)
             if self.device_reduce:
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
             else:
@@ -156,6 +165,84 @@ class GradSync:
         self._works = []
         if self.cuda:
             torch.cuda.current_stream(self.arena.device).wait_stream(self.comm_stream)
+
+
+class GraphedStep:
+    """One train step (dropout draw, forward, both losses, backward, gradient exchange, AdamW, weight repack)
+    replayed from HIP graphs on static input buffers: what bench.py times and what the trainer runs after its
+    first eager steps, so both exercise one schedule.
+
+    One replica: ONE graph of the whole step.  With a GradSync (N > 1 ranks): FOUR graphs with the gradient
+    exchanges between them, each exchange on the communication stream while the next graph runs:
+    [forward + decoder backward] -> all-reduce of the decoder's range -> [encoder head + deep blocks backward] ->
+    all-reduce of their range -> [shallow blocks + stem backward] -> all-reduce of the rest -> [AdamW].
+    Captured in thread-local mode: other threads of the process (a DataLoader's pin-memory thread, the process
+    group's watchdog) may call into the HIP runtime while this thread captures."""
+
+    def __init__(self, eng, batch_size, lr, loss_scale=1.0, sync=None):
+        self.eng, self.batch_size, self.lr, self.loss_scale, self.sync = eng, float(batch_size), lr, loss_scale, sync
+        self.graphs, self.inputs, self.out = None, None, None
+
+    def capture(self, x, labels, eps):
+        """x, labels, eps: tensors of the step's shapes and dtypes (their values are not used)."""
+        eng, sync = self.eng, self.sync
+        self.inputs = (torch.empty_like(x), torch.empty_like(labels), torch.empty_like(eps))
+        gx, gl, ge = self.inputs
+        eng.grad_ready = None
+        eng.pack_weights(force=True)
+        torch.cuda.synchronize()
+        saved = eng.step_count
+        mode = {"capture_error_mode": "thread_local"}
+        if sync is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **mode):
+                eng.random_mask()
+                eng._packed_version = -1             # the captured step repacks the weights it updated last time
+                self.out = eng.forward_backward(gx, gl, ge, self.batch_size, self.loss_scale)
+                eng.adamw_step(self.lr)
+            self.graphs = [g]
+        else:
+            assert sync.groups is not None and len(sync.groups) == 3, "the default exchange plan"
+            assert sync.groups[1][-1] == "enc.blk%d" % eng.enc_split, "graph boundaries follow the exchange groups"
+            gs = [torch.cuda.CUDAGraph() for _ in range(4)]
+            mode["pool"] = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(gs[0], **mode):
+                eng.random_mask()
+                eng._packed_version = -1
+                self.out = eng.forward_backward_decoder(gx, gl, ge, self.batch_size, self.loss_scale)
+            with torch.cuda.graph(gs[1], **mode):
+                eng.enc_backward(eng.enc["dh"], part="upper")
+            with torch.cuda.graph(gs[2], **mode):
+                eng.enc_backward(eng.enc["dh"], part="lower")
+            with torch.cuda.graph(gs[3], **mode):
+                eng.adamw_step(self.lr)
+            self.graphs = gs
+        eng.step_count = saved
+        return self
+
+    def run(self, x, labels, eps):
+        """Copies the inputs in and enqueues the step; returns the reconstruction (a static buffer)."""
+        for dst, src in zip(self.inputs, (x, labels, eps)):
+            dst.copy_(src)
+        self.replay()
+        return self.out
+
+    def replay(self):
+        eng, sync = self.eng, self.sync
+        if sync is None:
+            self.graphs[0].replay()
+        else:
+            sync.begin_step()
+            self.graphs[0].replay()
+            sync.group_ready(0)                          # the decoder's range
+            self.graphs[1].replay()
+            sync.group_ready(1)                          # encoder head + deep blocks
+            self.graphs[2].replay()
+            sync.group_ready(2)                          # shallow blocks + stem
+            sync.finish()
+            self.graphs[3].replay()
+        eng.step_count += 1
+        eng.params_changed()                             # host-side version: engines that share the weights repack
 
 
 def broadcast_state(engine, src=0, group=None):

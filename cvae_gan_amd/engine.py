@@ -727,9 +727,17 @@ class Engine:
                        beta=None if gated else self.params[prefix + ".bias"])
 
     def _ready(self, stage):
+        """Report that every gradient of `stage` has been enqueued.  Part of them may still be running on the
+        weight-gradient side streams: the listener gets one event per side stream to wait for, on whatever
+        stream it exchanges on, and this (the input-gradient) stream goes on without joining them."""
         if self.grad_ready is not None:
-            self._join()
-            self.grad_ready(stage)
+            events = []
+            if self._side_dirty:
+                for side in self._side:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append(ev)
+            self.grad_ready(stage, events)
 
     def _fwd(self, g, x, y, bias=None, stat_partials=None, **kw):
         if stat_partials is not None:

@@ -84,10 +84,12 @@ def test_trainer_two_ranks_share_one_gpu(tmp_path):
     Rank 0 alone prints and writes; the global batch of 16 is split 8 + 8."""
     out = _run_ranks(["-m", "cvae_gan_amd.starter", "--dataset", "Synth", "--data_dir", str(tmp_path / "none"),
                       "--data_size", "64", "--pix_dim", "32", "--y_dim", "4", "--z_dim", "8", "--batch_size", "16",
-                      "--epoch", "1", "--max_iters", "3", "--lrG", "1e-3", "--worker", "0", "--gpus", "0",
+                      "--epoch", "2", "--max_iters", "6", "--lrG", "1e-3", "--worker", "0", "--gpus", "0",
                       "--save_dir", str(tmp_path / "ck"), "--result_dir", str(tmp_path / "res")], 2,
                      extra_env={"CVG_DDP_BACKEND": "gloo", "CVG_DDP_SHARE_GPU": "1"})
+    # (steps 3..6 are replayed from the four graphs of ddp.GraphedStep with the exchanges between them)
     assert "Training finish" in out[0] and "Training finish" not in out[1]
+    assert "capture of the train step failed" not in out[0]
     d = os.path.join(str(tmp_path / "ck"), "VAE_data_Synth_pix_32_batch_16_embed_8")
     enc = torch.load(os.path.join(d, "Synth_encoder.pkl"), weights_only=True)
     assert len(enc) == 68 and all(torch.isfinite(v.float()).all() for v in enc.values())
@@ -106,3 +108,23 @@ def test_gan_trainer_two_ranks(tmp_path):
     for name in ("encoder", "decoder", "discriminator", "classifier"):
         sd = torch.load(os.path.join(d, "Synth_%s.pkl" % name), weights_only=True)
         assert all(torch.isfinite(v.float()).all() for v in sd.values()), name
+
+
+def test_bench_two_ranks_one_json_line():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), both ranks on
+    this GPU with the gloo transport: the four-graph schedule with the exchanges between the graphs runs, rank 0
+    prints exactly one JSON line for the two-rank job, and the losses are finite."""
+    import json
+    env = dict(os.environ, CVG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c2",
+           "--batch", "32", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64
+    assert d["config"]["launch"] == "hip-graph" and d["scaling"] == "weak"
+    assert all(v == v and abs(v) < 1e6 for v in d["losses_last_step"].values())
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

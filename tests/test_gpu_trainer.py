@@ -150,6 +150,44 @@ def test_trainer_graph_replay_equals_eager_launches(tmp_path):
         assert torch.equal(a[k], b[k]), k
 
 
+def test_trainer_graph_capture_with_loader_workers(tmp_path):
+    """train.sh passes --worker 48: the DataLoader's worker processes and its pin-memory thread (which allocates
+    pinned host memory through the HIP runtime) are alive while the third step is captured.  The capture runs in
+    thread-local mode, so it succeeds, and the run equals eager launches bit for bit."""
+    from cvae_gan_amd.cvae import CVAE
+    runs = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = CVAE(_args(tmp_path / ("w%d" % graph), epoch=2, graph=graph, worker=2))
+        m.train()
+        assert (m._graph is not None) == graph
+        sd = dict(m.engine.state_dict("encoder"))
+        sd.update(m.engine.state_dict("decoder"))
+        runs.append((sd, list(m.train_hist["LL_loss"])))
+    (a, lla), (b, llb) = runs
+    assert len(lla) == 8 and lla == llb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_trainer_falls_back_to_eager_when_capture_fails(tmp_path, monkeypatch):
+    """A failed capture must not end the run: the trainer reports it and goes on launching eagerly."""
+    from cvae_gan_amd import ddp
+    from cvae_gan_amd.cvae import CVAE
+
+    def broken(self, *a, **k):
+        raise RuntimeError("capture refused (test)")
+
+    monkeypatch.setattr(ddp.GraphedStep, "capture", broken)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = CVAE(_args(tmp_path, epoch=2))
+    m.train()
+    assert m._graph is None and m._use_graph is False
+    assert len(m.train_hist["LL_loss"]) == 8 and all(np.isfinite(m.train_hist["LL_loss"]))
+
+
 def test_device_prefetcher_matches_host_pipeline(tmp_path):
     """uint8 batches normalised on the GPU (cvg_image_u8_to_f32 behind pinned double buffers) equal
     ToTensor + Normalize(.5, .5) of the same bytes (reference datasets.py:14-18), batch after batch."""
