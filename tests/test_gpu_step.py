@@ -97,33 +97,53 @@ def _bf16_check(rows, eng, ref, act_cos, loss_tol, grads):
     return bad
 
 
+# bf16 bars per case, for the statistics form that ships (sums about the first row, cvg_bn_stats).  Where a bar is
+# looser than 0.998 / 3e-2 / 0.98 the reason is named; tools/bf16_chain.py prints the whole backward chain.
+RAW_BARS = {
+    # raw initialisation: the decoder's pre-tanh activations reach +-60, so the loss gradient (1 - tanh^2) lives on
+    # the few unsaturated pixels, where a bf16-sized error of the pre-activation (+-0.5) changes it by a factor of e.
+    # tiny_p16_ngf8 (16 x 16, batch 4) has so few of them that the direction of everything behind `pre` is decided
+    # by rounding: three numerically equivalent variants of this code base measured aggregate gradient cosines of
+    # +0.98, -0.33 and -0.96 (this tree: -0.31), while the forward pass and the losses hold.  Its gradients are
+    # therefore not judged here; the conditioned test below judges them.
+    "tiny_p16_ngf8": dict(act_cos=0.98, loss_tol=3e-2, grads=None),
+    "ragged_p32_ngf8": dict(act_cos=0.998, loss_tol=5e-2,        # KL: log sigma reaches +-3 and exp() turns its bf16 rounding into 2 % of sigma^2
+                            grads=dict(agg_enc=0.97, big_enc=0.97, agg_dec=0.97, big_dec=0.97, any=0.93)),   # measured 0.993 / 0.993, worst tensor 0.972
+    "c2_p32_ngf64": dict(act_cos=0.99, loss_tol=3e-2,            # the saturated tail: cos(pre-tanh) 0.997, cos(loss gradient) 0.90 with bf16 storage of the weights alone at 0.97
+                         grads=dict(agg_enc=0.92, big_enc=0.90, agg_dec=0.92, big_dec=0.90, any=0.88)),      # measured 0.960 / 0.954, worst tensor 0.924
+    "deep5_p64_ngf8": dict(act_cos=0.998, loss_tol=3e-2,
+                           grads=dict(agg_enc=0.95, big_enc=0.95, agg_dec=0.97, big_dec=0.97, any=0.85)),    # measured 0.975 / 0.994, worst tensor 0.893 (stem BatchNorm bias)
+}
+CONDITIONED_BARS = {
+    # encoder bounds: the batch-4 cases with a 1 x 1 / 2 x 2 final map lose the direction at ONE place, the backward pass
+    # of the head's BatchNorm1d (4 samples per feature: g - mean g - xhat mean(g xhat) keeps 2 of 4 dimensions and
+    # cancels to the last bits of xhat): cos(d f1) 0.9996 -> cos(d f0) 0.90 on deep5_p64_ngf8, unchanged with f0, f1
+    # and their gradients kept in f32 (tried), so it is the 1 % of bf16 error the 15 layers in front accumulate in
+    # xhat, not this layer's arithmetic; everything behind it carries that cosine.  c2_p32_ngf64 (batch 8) drops
+    # there to 0.973, which bf16 storage of the weights and the image alone already does to the f32 oracle (0.975).
+    "tiny_p16_ngf8": dict(agg_enc=0.98, big_enc=0.98, agg_dec=0.998, big_dec=0.995, any=0.95),     # measured 0.995 / 0.9997, worst 0.983
+    "ragged_p32_ngf8": dict(agg_enc=0.98, big_enc=0.98, agg_dec=0.998, big_dec=0.995, any=0.95),   # measured 0.993 / 0.9999, worst 0.975
+    "c2_p32_ngf64": dict(agg_enc=0.95, big_enc=0.94, agg_dec=0.998, big_dec=0.995, any=0.90),      # measured 0.966 / 0.9996, worst 0.939
+    "deep5_p64_ngf8": dict(agg_enc=0.85, big_enc=0.85, agg_dec=0.998, big_dec=0.995, any=0.5),     # measured 0.894 / 0.9996, worst 0.636 (stem BatchNorm bias, 8 values)
+}
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_step_parity_bf16(name):
-    """bf16 activations / weight shadows against the f32 oracle at the reference's own initialisation: the
-    forward pass (cosine >= 0.98 per tensor), both losses (5e-2; the KL of the batch-6 case: log sigma reaches
-    +-3 there and exp() turns its bf16 rounding into 2 % of sigma^2) and the loss gradient.
-    Parameter gradients are printed but NOT judged here.  At this point the decoder's pre-tanh activations
-    reach +-60, so the loss gradient (1 - tanh^2) lives on the few unsaturated pixels, where a bf16-sized
-    error of the pre-activation (+-0.5) changes it by a factor of e; behind the decoder's transposed
-    convolutions the direction of everything upstream is decided by those pixels.  Measured on
-    tiny_p16_ngf8 (batch 4) with two forms of the BatchNorm statistics that agree to 1e-6 in f32: aggregate
-    gradient cosine +0.98 with one and -0.33 with the other.  The conditioned variant below is the
-    gradient test."""
+    """bf16 activations / weight shadows against the f32 oracle at the reference's own initialisation: the forward
+    pass, both losses, the loss gradient and (except on the 16 x 16 batch-4 case) the parameter gradients, with the
+    bars of RAW_BARS."""
     rows, eng, ref = run_parity(name, torch.bfloat16)
-    bad = _bf16_check(rows, eng, ref, act_cos=0.98, loss_tol=5e-2, grads=None)
+    bad = _bf16_check(rows, eng, ref, **RAW_BARS[name])
     assert not bad, "\n" + format_rows(bad)
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_step_parity_bf16_conditioned(name):
     """Same comparison with every decoder weight scaled by 0.55 (both sides), which brings the pre-tanh
-    activations to O(1): forward cosine >= 0.999, losses 5e-2 (the KL term, see above), decoder gradients
-    >= 0.995 as one vector and >= 0.99 per tensor, encoder gradients >= 0.85 as one vector and per tensor of
-    at least 4096 elements, every tensor >= 0.5.  The encoder bounds are set by the smallest cases (batch 4
-    with a 2 x 2 or 1 x 1 final map: the deepest BatchNorms see 16 or 4 values per channel and their backward
-    pass projects most of the incoming gradient away): measured 0.894 / 0.991 aggregate on deep5_p64_ngf8
-    with the two statistics forms named above, 0.966 on the reference-width case (batch 8) with both, and
-    >= 0.97 per tensor at the benchmark width with batch 32 (tests/test_gpu_fullsize.py)."""
+    activations to O(1): forward cosine >= 0.999, losses 5e-2 (the KL term of the batch-6 case), gradients with the
+    bars of CONDITIONED_BARS; at the benchmark width with batch 32 and 256 every tensor is held to >= 0.97
+    (tests/test_gpu_fullsize.py)."""
     def shrink(state):
         e, d = state
         for k in d:
@@ -131,8 +151,7 @@ def test_step_parity_bf16_conditioned(name):
                 d[k] = d[k] * 0.55
         return e, d
     rows, eng, ref = run_parity(name, torch.bfloat16, state_fn=shrink)
-    bad = _bf16_check(rows, eng, ref, act_cos=0.999, loss_tol=5e-2,
-                      grads=dict(agg_enc=0.85, big_enc=0.85, agg_dec=0.995, big_dec=0.99, any=0.5))
+    bad = _bf16_check(rows, eng, ref, act_cos=0.999, loss_tol=5e-2, grads=CONDITIONED_BARS[name])
     assert not bad, "\n" + format_rows(bad)
 
 
