@@ -28,3 +28,20 @@ timing: $(LIB)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build_exp/lib_timing.so $(SRC_DIR)/api.o $(SRC_DIR)/igemm.o build_exp/conv_patch_timing.o $(SRC_DIR)/elementwise.o
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value tools/mfma_peak.hip -o build_exp/mfma_peak
 .PHONY: timing
+
+# Host-side sanitizer configuration: the library's host code (validation, planning, launch set-up) compiled with
+# AddressSanitizer + UndefinedBehaviorSanitizer (device code as usual) and linked into tests/native/abi_check.cpp,
+# which calls every planning query over the networks' shapes and the rejection paths; runs on the CPU.
+ASAN_DIR := build_exp/asan
+ASAN_FLAGS := $(FLAGS) -g -fno-omit-frame-pointer -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize-recover=undefined
+$(ASAN_DIR)/%.o: $(SRC_DIR)/%.hip $(SRC_DIR)/common.h $(SRC_DIR)/gemm_util.h $(SRC_DIR)/conv_patch.h include/cvaegan.h
+	@mkdir -p $(ASAN_DIR)
+	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
+$(ASAN_DIR)/abi_check.o: tests/native/abi_check.cpp include/cvaegan.h
+	@mkdir -p $(ASAN_DIR)
+	/opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -Iinclude -fsanitize=address,undefined -fno-sanitize-recover=undefined -c $< -o $@
+$(ASAN_DIR)/abi_check: $(patsubst $(SRC_DIR)/%.hip,$(ASAN_DIR)/%.o,$(SRCS)) $(ASAN_DIR)/abi_check.o
+	$(HIPCC) --offload-arch=$(ARCH) -fsanitize=address,undefined -fno-gpu-sanitize $^ -o $@
+asan: $(ASAN_DIR)/abi_check
+	ASAN_OPTIONS=detect_leaks=0 $(ASAN_DIR)/abi_check
+.PHONY: asan

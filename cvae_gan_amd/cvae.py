@@ -158,7 +158,12 @@ class CVAE(object):
         torch.save(self.engine.state_dict("decoder"), os.path.join(save_dir, self.dataset + "_decoder.pkl"))
         if self.gan is not None:
             torch.save(self.gan.D.trunk.state_dict("critic"), os.path.join(save_dir, self.dataset + "_discriminator.pkl"))
-            torch.save(self.gan.C.trunk.state_dict("critic"), os.path.join(save_dir, self.dataset + "_classifier.pkl"))
+            # the classifier's file also carries the per-class feature centres that L_GC pulls the samples towards
+            # (state of the loss, not of a network: without them a resumed run starts that term from nothing)
+            csd = self.gan.C.trunk.state_dict("critic")
+            csd["gan.centres"] = self.gan.centres.detach().cpu().clone()
+            csd["gan.centres_seen"] = self.gan.centres_seen.detach().cpu().clone()
+            torch.save(csd, os.path.join(save_dir, self.dataset + "_classifier.pkl"))
         with open(os.path.join(save_dir, self.dataset + "_history.pkl"), "wb") as f:
             pickle.dump(self.train_hist, f)
 
@@ -170,7 +175,12 @@ class CVAE(object):
         if self.gan is not None:
             for name, critic in (("discriminator", self.gan.D), ("classifier", self.gan.C)):
                 if os.path.exists(base + "_%s.pkl" % name):
-                    critic.trunk.load_state(torch.load(base + "_%s.pkl" % name, map_location="cpu", weights_only=True))
+                    sd = torch.load(base + "_%s.pkl" % name, map_location="cpu", weights_only=True)
+                    centres, seen = sd.pop("gan.centres", None), sd.pop("gan.centres_seen", None)
+                    if centres is not None and seen is not None and tuple(centres.shape) == tuple(self.gan.centres.shape):
+                        self.gan.centres.copy_(centres)
+                        self.gan.centres_seen.copy_(seen)
+                    critic.trunk.load_state(sd)
 
     # ------------------------------------------------------------------ training
     def _to_device(self, imgs, labels):

@@ -174,6 +174,7 @@ class CVAEGAN:
     def read_losses(self):
         vae = self.vae.read_losses()         # raises if a class label outside [0, y) reached the encoder
         kl, ll = vae["KL"], vae["LL"]
-        ld, lgd, lpd = self.D.losses.tolist()
-        lc, lgc, lpc = self.C.losses.tolist()
+        from . import ddp
+        # like KL / LL in the trainer's log: the mean over the ranks (each rank's value is that of its shard)
+        ld, lgd, lpd, lc, lgc, lpc = ddp.allreduce_mean(torch.cat([self.D.losses, self.C.losses])).tolist()
         return dict(KL=kl, LL=ll, D=ld, C=lc, GD=lgd, GC=lgc, PD=lpd, PC=lpc)

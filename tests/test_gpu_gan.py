@@ -129,6 +129,9 @@ def test_gan_trainer_runs_and_checkpoints(tmp_path):
     m2 = CVAE(_args(tmp_path, resume=True, gan_type="CVAEGAN"))
     for k, v in m.gan.C.trunk.state_dict("critic").items():
         assert torch.equal(v, m2.gan.C.trunk.state_dict("critic")[k]), k
+    # the per-class feature centres of L_GC travel with the classifier's checkpoint
+    assert int(m.gan.centres_seen.sum()) > 0
+    assert torch.equal(m.gan.centres, m2.gan.centres) and torch.equal(m.gan.centres_seen, m2.gan.centres_seen)
 
 
 def test_gan_step_bf16_tracks_f32():

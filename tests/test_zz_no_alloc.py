@@ -53,3 +53,43 @@ def test_static_scratch_rejects_wide_rows():
     ws = torch.zeros(2 * ops.bn_stats_blocks(16, 1032) * 1032, device="cuda")
     ops.bn_stats(x, 16, 1032, stats, None, None, None, ws)       # the workspace form takes it
     torch.cuda.synchronize()
+
+
+_CAPTURE_FIRST = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from cvae_gan_amd import ops
+M, C = 4096, 64
+g = torch.Generator(device="cuda").manual_seed(3)
+x = (torch.randn(M, C, device="cuda", generator=g) * 2 + 0.5).to(torch.bfloat16)
+stats = torch.zeros(2, C, device="cuda")
+rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+nbt = torch.zeros((), dtype=torch.long, device="cuda")
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):                      # the library's FIRST static-scratch call of this process
+    ops.bn_stats_static(x, M, C, stats, rm, rv, nbt)
+graph.replay()
+graph.replay()
+torch.cuda.synchronize()
+ws = torch.zeros(2 * ops.bn_stats_blocks(M, C) * C, device="cuda")
+s2 = torch.zeros(2, C, device="cuda")
+ops.bn_stats(x, M, C, s2, None, None, None, ws)
+torch.cuda.synchronize()
+assert torch.equal(stats, s2), (stats - s2).abs().max()
+assert int(nbt) == 2, int(nbt)
+print("capture-first ok")
+"""
+
+
+def test_first_call_inside_graph_capture():
+    """The header names HIP-graph capture as a use: here the process's first cvg_bn_stats_static call (the one that
+    looks the scratch array's address up) happens INSIDE a capture, in a fresh process; the replays must equal the
+    workspace form bit for bit and advance the batch counter once each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _CAPTURE_FIRST % root], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=170)
+    assert p.returncode == 0 and "capture-first ok" in p.stdout, p.stdout[-3000:]
