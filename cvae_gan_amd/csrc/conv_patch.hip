@@ -1719,9 +1719,7 @@ int patch_wgrad_launch(const cvg_conv_desc* d, const PatchWgradPlan& p, const vo
         else CVG_FAIL("patch_wgrad: no kernel for WN %d taps/wave %d", p.WN, tpw);
     }
     if (rc) return rc;
-    const int64_t n = (int64_t)map->n_valid * (a.k_ld / 4);
-    const int zg = wgrad_reduce_zg(n, p.nsplit);
-    wgrad_reduce<<<ceil_div(n, 256 / zg), 256, 0, s>>>(ws, grad, *map, a.n_rows, a.k_ld, p.nsplit, accumulate, zg);
+    launch_wgrad_reduce(ws, grad, map, a.n_rows, a.k_ld, p.nsplit, accumulate, s);
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -153,3 +153,83 @@ static inline int wgrad_reduce_zg(int64_t outputs4, int nsplit) {
     while (zg < 8 && outputs4 * zg < 131072 && nsplit >= 8 * zg) zg *= 2;
     return zg;
 }
+
+// The same for the layouts whose canonical tensor is contiguous along the NINE taps of one (n, c) pair: convolution
+// weights W[n][c][3][3] reduced from slabs [n][tap * kd + c] (pattern A) or from slabs [tap * nd + n][c] (pattern B,
+// the one-tap GEMMs of the low-resolution up-convolution gradients).  wgrad_reduce gives every thread four
+// consecutive k, i.e. four c, and stores them 36 bytes apart: one 4-byte store per 64-byte segment, which for the
+// 2.4 M-element layers costs more than reading the slabs.  Here a workgroup takes 64 consecutive c of a few n: each
+// tap's slab values are read coalesced along c, the sums meet in LDS, and the 64 * 9 canonical floats of an n leave
+// as one contiguous run.  zg (1, 2 or 4) slab ranges per pair share the workgroup and are added in range order.
+template <int T>
+static __global__ void __launch_bounds__(256) wgrad_reduce_taps(const float* __restrict__ ws, float* __restrict__ grad,
+                                                                int n_valid, int c_valid, int RN, size_t RT, size_t zstride,
+                                                                int SN, int nsplit, int accumulate, int zg) {
+    __shared__ float sm[4][64 * T];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nb = 4 / zg, nl = grp / zg, zi = grp - nl * zg;
+    const int cblocks = (c_valid + 63) >> 6;
+    const int nblk = blockIdx.x / cblocks, cb = blockIdx.x - nblk * cblocks;
+    const int n = nblk * nb + nl, c = cb * 64 + cl;
+    float s[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) s[t] = 0.f;
+    if (n < n_valid && c < c_valid) {
+        const float* p = ws + (size_t)n * RN + c;
+        const int per = (nsplit + zg - 1) / zg;
+        int z = zi * per;
+        const int z_end = min(nsplit, z + per);
+        for (; z + 2 <= z_end; z += 2) {           // two slabs (18 loads) in flight, added in slab order
+            float v[2][T];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[u][t] = p[(size_t)(z + u) * zstride + t * RT];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) s[t] += v[u][t];
+        }
+        if (z < z_end) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) s[t] += p[(size_t)z * zstride + t * RT];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) sm[grp][cl * T + t] = s[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * 64 * T; i += 256) {
+        const int nl_ = i / (64 * T), j = i - nl_ * (64 * T);
+        const int n_ = nblk * nb + nl_, c_ = cb * 64 + j / T;
+        if (n_ >= n_valid || c_ >= c_valid) continue;
+        float v = 0.f;
+        for (int q = 0; q < zg; ++q) v += sm[nl_ * zg + q][j];
+        const size_t idx = (size_t)n_ * SN + (size_t)cb * 64 * T + j;
+        grad[idx] = accumulate ? grad[idx] + v : v;
+    }
+}
+
+// slabs -> canonical gradient with whichever of the two kernels fits the layout
+static inline void launch_wgrad_reduce(const float* ws, float* grad, const cvg_wmap* map, int n_rows, int k_ld, int nsplit,
+                                       int accumulate, hipStream_t s) {
+    const bool pat_a = map->nd == 1 && map->tap_mode == 0 && map->ka == 1 && map->kb == 9 && map->ntaps == 9 &&
+                       map->nr_valid == 0 && map->nb == 0;
+    const bool pat_b = map->ntaps == 1 && map->na == 1 && map->ka == 0 && map->kb == 9 && map->nr_valid == 0 &&
+                       map->tap_mode == 0 && map->n_valid == 9 * map->nd;
+    if (pat_a || pat_b) {
+        const int n_valid = pat_a ? map->n_valid : map->nd, c_valid = map->kc_valid;
+        const size_t RT = pat_a ? (size_t)map->kd : (size_t)map->nd * k_ld;
+        const int SN = pat_a ? map->na : map->nb;
+        const int64_t pairs = (int64_t)n_valid * c_valid;
+        int zg = 1;
+        while (zg < 4 && pairs * zg < 131072 && nsplit >= 8 * zg) zg *= 2;
+        const int nb = 4 / zg;
+        const int64_t blocks = (int64_t)ceil_div(n_valid, nb) * ceil_div(c_valid, 64);
+        wgrad_reduce_taps<9><<<(int)blocks, 256, 0, s>>>(ws, grad, n_valid, c_valid, k_ld, RT, (size_t)n_rows * k_ld, SN, nsplit,
+                                                         accumulate, zg);
+        return;
+    }
+    const int64_t n = (int64_t)map->n_valid * (k_ld / 4);
+    const int zg = wgrad_reduce_zg(n, nsplit);
+    wgrad_reduce<<<ceil_div(n, 256 / zg), 256, 0, s>>>(ws, grad, *map, n_rows, k_ld, nsplit, accumulate, zg);
+}

@@ -845,9 +845,7 @@ int cvg_conv_wgrad(const cvg_conv_desc* d, const void* x, const void* dy, int32_
     hipStream_t s = (hipStream_t)stream;
     int rc = d->dtype == CVG_BF16 ? launch_wgrad<bf16>(p, a, s) : launch_wgrad<float>(p, a, s);
     if (rc) return rc;
-    const int64_t n = (int64_t)map->n_valid * (p.k_ld / 4);
-    const int zg = wgrad_reduce_zg(n, p.nsplit);
-    wgrad_reduce<<<ceil_div(n, 256 / zg), 256, 0, s>>>(a.ws, grad, *map, p.n_rows, p.k_ld, p.nsplit, accumulate, zg);
+    launch_wgrad_reduce(a.ws, grad, map, p.n_rows, p.k_ld, p.nsplit, accumulate, s);
     CVG_LAUNCH_CHECK();
     return 0;
 }

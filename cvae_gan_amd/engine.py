@@ -1000,11 +1000,16 @@ class Engine:
             d_x = d["d_x0"] if i == 0 else d["ups"][i - 1]["d_y"]
             if self.lowres_up_bwd:
                 x_in = d["x0"] if i == 0 else d["ups"][i - 1]["y"]
-                with self._branch():
-                    ops.colsum(up["d_y"], M, up["cout"], up["cout"], self.grads[up["key"] + "bias"], self.red_ws_side)
                 ops.upsample_taps_bwd(up["d_y"], up["z"], B, up["h"], up["h"], up["cout"])
                 with self._branch():
                     self._wgrad(up["wg_low"], x_in, up["z"], 9 * up["cout"])
+                    # the bias gradient sum_p d_y[p] from z as well: the up-sampling weights of every position sum
+                    # to 1, so sum_q z_t[q] = sum_p d_y[p] for every tap t; the centre tap's columns of z are a
+                    # quarter of the rows of d_y
+                    if not self._frozen:
+                        N = up["cout"]
+                        ops.colsum(up["z"].view(-1)[4 * N:], B * up["h"] * up["h"], N, 9 * N,
+                                   self.grads[up["key"] + "bias"], self.red_ws_side)
                 self._fwd(up["dg_low"], up["z"], d_x)
                 continue
             with self._branch():
