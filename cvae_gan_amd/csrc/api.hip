@@ -26,6 +26,7 @@ const CvgSwitches& cvg_switches() {
         w.wgrad_s2_gather = on("CVG_WGRAD_S2_GATHER");
         w.wgrad_v1 = on("CVG_WGRAD_V1");
         w.wgrad_4w = on("CVG_WGRAD_4W");
+        w.wgrad_wide = on("CVG_WGRAD_WIDE");
         w.bn_raw_sums = on("CVG_BN_RAW_SUMS");
         w.split_finalize = on("CVG_SPLIT_FINALIZE");
         w.patch_wide = ch("CVG_PATCH_WIDE");
