@@ -110,12 +110,12 @@ class CVAE(object):
                                  device=self.device, seed=seed)
         self._sample_engine = None
         self.sync = None
-        # plain CVAE: after two eager steps the whole step (dropout draw, forward, backward, gradient exchange,
-        # AdamW, weight repack) is captured into HIP graphs and replayed on static input buffers: one graph on
-        # one replica, four with the exchanges between them on several (ddp.GraphedStep, the schedule bench.py
-        # times).  args.graph = False or CVG_TRAINER_EAGER: eager launches throughout.
-        self._use_graph = (self.gan is None and getattr(args, "graph", True)
-                           and os.environ.get("CVG_TRAINER_EAGER") is None)
+        # After two eager steps the whole step (dropout draw, forward, backward, gradient exchange, AdamW, weight
+        # repack) is captured into HIP graphs and replayed on static input buffers.  Plain CVAE: one graph on one
+        # replica, four with the exchanges between them on several (ddp.GraphedStep, the schedule bench.py times).
+        # Adversarial step: one graph, or two around the all-reduce of the three arenas (gan.GraphedGanStep).
+        # args.graph = False or CVG_TRAINER_EAGER: eager launches throughout.
+        self._use_graph = getattr(args, "graph", True) and os.environ.get("CVG_TRAINER_EAGER") is None
         self._graph, self._steps_done = None, 0
         if self.world > 1 and self.gan is not None:
             self.gan.broadcast_state()                            # the three arenas are summed after backward
@@ -234,6 +234,29 @@ class CVAE(object):
             self._graph = step
         return self._graph.run(x, cls, eps)
 
+    def gan_step(self, x, cls, eps, z_p, y_p):
+        """One adversarial step (cvae_gan_amd/gan.py) on this rank's rows: eager for the first two steps, then
+        replayed from HIP graphs; a failed capture leaves the trainer on eager launches."""
+        self._steps_done += 1
+        if self._use_graph and self._steps_done > 2:
+            if self._graph is None:
+                from .gan import GraphedGanStep
+                step = GraphedGanStep(self.gan, self.batch_size, self.lr, world=self.world)
+                try:
+                    self._graph = step.capture(x, cls, eps, z_p, y_p)
+                except Exception as exc:                 # noqa: BLE001 (whatever the runtime raised: fall back, do not die)
+                    torch.cuda.synchronize()
+                    self._use_graph = False
+                    for e in (self.gan.vae, self.gan.gen2, self.gan.D.trunk, self.gan.C.trunk):
+                        e._packed_version = -1
+                    self._print("HIP-graph capture of the adversarial step failed (%s: %s); continuing with eager launches"
+                                % (type(exc).__name__, exc))
+            if self._graph is not None:
+                return self._graph.run(x, cls, eps, z_p, y_p)
+        self.gan.vae.random_mask()
+        self.gan.gen2.random_mask()
+        return self.gan.train_step(x, cls, eps, z_p, y_p, float(self.batch_size), self.lr, world=self.world)
+
     def read_losses(self):
         """The losses of the whole (global) batch: the mean of the ranks' values."""
         kl, ll, bad = ddp.allreduce_mean(self.engine.losses[:3]).tolist()
@@ -261,12 +284,10 @@ class CVAE(object):
             for it, (x, cls) in enumerate(self.batches()):
                 eps.normal_(generator=self._eps_gen)
                 if self.gan is not None:
-                    eng.random_mask()
                     z_p.normal_(generator=self._eps_gen)
                     y_p.zero_()
                     y_p[rows, torch.randint(0, self.y_dim, (self.local_batch,), device=self.device, generator=self._eps_gen)] = 1
-                    self.gan.gen2.random_mask()
-                    self.gan.train_step(x, cls, eps, z_p, y_p, float(self.batch_size), self.lr, world=self.world)
+                    self.gan_step(x, cls, eps, z_p, y_p)
                 else:
                     self.train_step(x, cls, eps)
                 iters += 1

@@ -178,3 +178,71 @@ class CVAEGAN:
         # like KL / LL in the trainer's log: the mean over the ranks (each rank's value is that of its shard)
         ld, lgd, lpd, lc, lgc, lpc = ddp.allreduce_mean(torch.cat([self.D.losses, self.C.losses])).tolist()
         return dict(KL=kl, LL=ll, D=ld, C=lc, GD=lgd, GC=lgc, PD=lpd, PC=lpc)
+
+
+class GraphedGanStep:
+    """The adversarial step (dropout draws, the four networks' forward and backward passes, three AdamW
+    updates, weight repacks) replayed from HIP graphs on static input buffers.  One replica: ONE graph.
+    Several replicas: [forward + backward] -> all-reduce of the three gradient arenas -> [AdamW], i.e. two
+    graphs with the exchange between them.  Captured in thread-local mode, like ddp.GraphedStep."""
+
+    def __init__(self, net, batch_size, lr, world=1):
+        self.net, self.batch_size, self.lr, self.world = net, float(batch_size), lr, world
+        self.graphs, self.inputs, self.out = None, None, None
+
+    def _engines(self):
+        n = self.net
+        return (n.vae, n.gen2, n.D.trunk, n.C.trunk)
+
+    def capture(self, x, labels, eps, z_p, y_p):
+        """Tensors of the step's shapes and dtypes (their values are not used)."""
+        net = self.net
+        self.inputs = tuple(torch.empty_like(t) for t in (x, labels, eps, z_p, y_p))
+        gx, gl, ge, gz, gy = self.inputs
+        owners = (net.vae, net.D.trunk, net.C.trunk)             # the engines that own an optimiser state
+        for e in self._engines():
+            e.grad_ready = None
+            e.pack_weights(force=True)
+        torch.cuda.synchronize()
+        saved = [e.step_count for e in owners]
+        mode = {"capture_error_mode": "thread_local"}
+
+        def fwd_bwd():
+            net.vae.random_mask()
+            net.gen2.random_mask()
+            for e in self._engines():
+                e._packed_version = -1                           # the captured step repacks what it updated last time
+            self.out = net.forward_backward(gx, gl, ge, gz, gy, self.batch_size, loss_scale=1.0 / self.world)
+
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **mode):
+                fwd_bwd()
+                net.adamw_step(self.lr)
+            self.graphs = [g]
+        else:
+            gs = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+            mode["pool"] = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(gs[0], **mode):
+                fwd_bwd()
+            with torch.cuda.graph(gs[1], **mode):
+                net.adamw_step(self.lr)
+            self.graphs = gs
+        for e, c in zip(owners, saved):
+            e.step_count = c
+        return self
+
+    def run(self, x, labels, eps, z_p, y_p):
+        """Copies the inputs in and enqueues the step; returns (reconstruction, sample), static buffers."""
+        for dst, src in zip(self.inputs, (x, labels, eps, z_p, y_p)):
+            dst.copy_(src)
+        net = self.net
+        self.graphs[0].replay()
+        if self.world > 1:
+            net.all_reduce_grads()
+            self.graphs[1].replay()
+        for e in (net.vae, net.D.trunk, net.C.trunk):
+            e.step_count += 1
+            e.params_changed()
+        return self.out
+
