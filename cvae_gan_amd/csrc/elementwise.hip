@@ -1040,6 +1040,17 @@ __device__ __forceinline__ float up_coef(int u, int i, int h) {       // coeffic
     up_src(unpad_reflect1(u, 2 * h), h, i0, i1, w0, w1);
     return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
 }
+// 8 channels held as raw 16-byte vectors (one of bf16, two of f32) -> floats
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 (&raw)[sizeof(T) / 2], float (&v)[8]);
+template <> __device__ __forceinline__ void unpack8<bf16>(const u32x4 (&raw)[1], float (&v)[8]) {
+    const bf16x8 a = __builtin_bit_cast(bf16x8, raw[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&raw)[2], float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = __uint_as_float(raw[0][i]); v[4 + i] = __uint_as_float(raw[1][i]); }
+}
 // A workgroup takes IXB consecutive positions of one low-resolution row and NCB 8-channel chunks (IXB * NCB = 256).
 // Pass 1 combines, per column of dY the row segment touches and per kernel row, the six rows of dY (one thread per
 // (column, chunk): six loads); the combinations meet in LDS; pass 2 combines six columns per position and kernel
@@ -1066,7 +1077,26 @@ __global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ d
         for (int k = 0; k < 3; ++k) wy[r][k] = ok ? up_coef(p + k, iy, h) : 0.f;
     }
     const T* base = dy + (size_t)b * H2 * W2 * N;
-    for (int idx = threadIdx.x; idx < NCOL * NCB; idx += 256) {
+    // (2 IXB + 4) NCB = 512 + 4 NCB <= 640 items: at most ITEMS per thread.  All of a thread's loads go out before
+    // the first sum: the kernel is bound by how many bytes a CU has in flight (three workgroups fit its LDS).
+    constexpr int ITEMS = 3, VW = (int)sizeof(T) / 2;           // VW 16-byte vectors per 8 channels: 1 (bf16) or 2 (f32)
+    u32x4 raw[ITEMS][6][VW];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = threadIdx.x + 256 * it;
+        const int col = idx / NCB, chn = idx - col * NCB;
+        const int px = 2 * ix0 - 2 + col;
+        const bool ok = idx < NCOL * NCB && px >= 0 && px < W2;
+        const T* src = base + (size_t)(ok ? px : 0) * N + (ok ? (ch0 + chn) * 8 : 0);      // absent items: any valid address
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = 0; q < VW; ++q) raw[it][r][q] = *(const u32x4*)(src + (size_t)ry[r] * W2 * N + q * (16 / sizeof(T)));
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = threadIdx.x + 256 * it;
+        if (idx >= NCOL * NCB) break;
         const int col = idx / NCB, chn = idx - col * NCB;
         const int px = 2 * ix0 - 2 + col;
         float s[3][8];
@@ -1075,15 +1105,15 @@ __global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ d
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
         if (px >= 0 && px < W2) {
-            float v[6][8];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) load8<T>(base + ((size_t)ry[r] * W2 + px) * N + (ch0 + chn) * 8, v[r]);
+            for (int r = 0; r < 6; ++r) {
+                float v[8];
+                unpack8<T>(raw[it][r], v);
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+                for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s[k][j] += wy[r][k] * v[r][j];
+                    for (int j = 0; j < 8; ++j) s[k][j] += wy[r][k] * v[j];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1095,38 +1125,38 @@ __global__ void __launch_bounds__(256) upsample_taps_bwd(const T* __restrict__ d
     __syncthreads();
     const int ixl = threadIdx.x / NCB, chn = threadIdx.x - ixl * NCB, ix = ix0 + ixl;
     if (ix >= w) return;
-    float acc[3][3][8];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[a][c][j] = 0.f;
+    float wxk[6][3];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const int px = 2 * ix - 2 + c;
         const bool okx = px >= 0 && px < W2;
-        float wxk[3];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) wxk[kx] = okx ? up_coef(px + kx, ix, w) : 0.f;
+        for (int kx = 0; kx < 3; ++kx) wxk[c][kx] = okx ? up_coef(px + kx, ix, w) : 0.f;
+    }
+    T* out = z + (((size_t)b * h + iy) * w + ix) * (size_t)(9 * N) + (ch0 + chn) * 8;
+    // one kernel row at a time: 24 accumulators live instead of 72, so that three workgroups fit a CU's registers
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 3; ++k) {
+        float acc[3][8];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[kx][j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
             const float* src = colsum + ((size_t)(k * NCOL + 2 * ixl + c) * NCB + chn) * 8;
             const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[k][kx][j] += wxk[kx] * lo[j];
-                    acc[k][kx][4 + j] += wxk[kx] * hi[j];
+                    acc[kx][j] += wxk[c][kx] * lo[j];
+                    acc[kx][4 + j] += wxk[c][kx] * hi[j];
                 }
         }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) store8<T>(out + (k * 3 + kx) * N, acc[kx]);
     }
-    T* out = z + (((size_t)b * h + iy) * w + ix) * (size_t)(9 * N) + (ch0 + chn) * 8;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) store8<T>(out + (k * 3 + kx) * N, acc[k][kx]);
 }
 
 // ---- forward of the up-convolution at LOW resolution --------------------------------------------------------
