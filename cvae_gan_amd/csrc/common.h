@@ -39,7 +39,7 @@ struct CvgSwitches {
     char patch_wide;          // CVG_PATCH_WIDE: '0' no eight-wave tiles, '1' 64-channel wave tiles
     char patch_persist;       // CVG_PATCH_PERSIST: '0' no walking workgroups, '1' on every eligible layer, '2' the
                               // walking kernel with one image group per workgroup; unset: the descriptor's flag
-    char patch_perm;          // CVG_PATCH_PERM: '0' natural lane order of the LDS reads
+    char patch_perm;          // CVG_PATCH_PERM: '0' natural lane order of the LDS reads, '1' no paired rows in 8 x 8 tiles
     int lds_extra;            // CVG_PATCH_LDS_EXTRA: bytes of LDS added per workgroup (occupancy experiments)
     int wgrad_wgs;            // CVG_WGRAD_WGS: workgroups a weight-gradient launch aims for
     bool tile_set; int tile[3];   // CVG_PATCH_TILE=th,tw,tb

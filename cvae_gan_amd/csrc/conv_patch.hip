@@ -24,6 +24,7 @@ constexpr int CK = 32;            // channels per staged chunk
 struct TileGeom {
     int TB, TH, TW, PH, PW, npx;           // npx = TB*TH*TW valid tile pixels
     int tiles_x;
+    int pair4;                             // tile pixels are numbered row r, row r + 4, row r + 1, ... (see tile_px)
     FastDiv div_tw, div_thw, div_pw, div_phw, div_tx;
 };
 
@@ -62,10 +63,18 @@ __device__ __forceinline__ bool pad_xy(int pad_mode, int H, int W, int& iy, int&
     return (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
 }
 
-// tile pixel q -> (tb, ty, tx)
+// tile pixel q -> (tb, ty, tx).  pair4 (8 x 8 tiles over a 10-pixel-wide patch): 16 consecutive q are row g and row
+// g + 4 of an image.  A ds_read_b128 lane group takes 16 consecutive q; its 16 patch pixels hit distinct banks when
+// their patch indices are distinct mod 16 (80-byte pitch), and rows g, g + 4 start 40 = 8 mod 16 pixels apart, so
+// the two half rows cover all 16 residues.  In natural order (rows g, g + 1: 10 apart) six of the sixteen collide.
 __device__ __forceinline__ void tile_px(const TileGeom& t, int q, int& tb, int& ty, int& tx) {
     tb = fdiv(q, t.div_thw);
     const int r = q - tb * (t.TH * t.TW);
+    if (t.pair4) {
+        ty = (r >> 4) + 4 * ((r >> 3) & 1);
+        tx = r & 7;
+        return;
+    }
     ty = fdiv(r, t.div_tw);
     tx = r - ty * t.TW;
 }
@@ -1282,7 +1291,7 @@ patch_dgrad_s2(const S2tArgs a) {
 // ---- host side -----------------------------------------------------------------------------
 void fill_tile(TileGeom& t, int TB, int TH, int TW, int KH, int KW, int tiles_x, int S = 1) {
     t.TB = TB; t.TH = TH; t.TW = TW; t.PH = (TH - 1) * S + KH; t.PW = (TW - 1) * S + KW;
-    t.npx = TB * TH * TW; t.tiles_x = tiles_x;
+    t.npx = TB * TH * TW; t.tiles_x = tiles_x; t.pair4 = 0;
     t.div_tw = make_fastdiv(TW); t.div_thw = make_fastdiv(TH * TW);
     t.div_pw = make_fastdiv(t.PW); t.div_phw = make_fastdiv(t.PH * t.PW);
     t.div_tx = make_fastdiv(tiles_x);
@@ -1532,6 +1541,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     }
 #endif
     fill_tile(a.t, p.TB, p.TH, p.TW, p.KH, p.KW, p.tiles_x);
+    a.t.pair4 = (p.TH == 8 && p.TW == 8 && p.PW == 10 && a.lane_perm && cvg_switches().patch_perm != '1') ? 1 : 0;
     // wave tile = 32 output channels x 128 pixels (64 for the narrowest layers): every wave streams
     // its own weight rows, so no weight byte crosses the L1 twice inside a workgroup.
     if (d->dtype == CVG_BF16) {
