@@ -67,7 +67,9 @@ __device__ __forceinline__ bool pad_xy(int pad_mode, int H, int W, int& iy, int&
 // g + 4 of an image.  A ds_read_b128 lane group takes 16 consecutive q; its 16 patch pixels hit distinct banks when
 // their patch indices are distinct mod 16 (80-byte pitch), and rows g, g + 4 start 40 = 8 mod 16 pixels apart, so
 // the two half rows cover all 16 residues.  In natural order (rows g, g + 1: 10 apart) six of the sixteen collide.
-__device__ __forceinline__ void tile_px(const TileGeom& t, int q, int& tb, int& ty, int& tx) {
+// (Only patch_fwd numbers its pixels this way; the other kernels use tile_px, which has no such case: one more
+// live value in the nine-tap weight-gradient kernel, which sits at 256 registers, would spill.)
+__device__ __forceinline__ void tile_px_fwd(const TileGeom& t, int q, int& tb, int& ty, int& tx) {
     tb = fdiv(q, t.div_thw);
     const int r = q - tb * (t.TH * t.TW);
     if (t.pair4) {
@@ -75,6 +77,12 @@ __device__ __forceinline__ void tile_px(const TileGeom& t, int q, int& tb, int& 
         tx = r & 7;
         return;
     }
+    ty = fdiv(r, t.div_tw);
+    tx = r - ty * t.TW;
+}
+__device__ __forceinline__ void tile_px(const TileGeom& t, int q, int& tb, int& ty, int& tx) {
+    tb = fdiv(q, t.div_thw);
+    const int r = q - tb * (t.TH * t.TW);
     ty = fdiv(r, t.div_tw);
     tx = r - ty * t.TW;
 }
@@ -263,7 +271,7 @@ patch_fwd(const PatchFwdArgs a) {
         int q = wm * WTM + mi * 32 + lpx;
         if (q >= t.npx) q = 0;
         int tb, ty, tx;
-        tile_px(t, q, tb, ty, tx);
+        tile_px_fwd(t, q, tb, ty, tx);
         abase[mi] = ((tb * t.PH + ty) * t.PW + tx) * PITCH + 8 * h * ES;
     }
 
@@ -403,7 +411,7 @@ patch_fwd(const PatchFwdArgs a) {
     int yo[PT];                                  // element offset of pixel q0 + i in y, -1: not stored
     if (a.row_fast) {                            // the PT pixels share one output row
         int tb, ty, tx;
-        tile_px(t, q0 < t.npx ? q0 : 0, tb, ty, tx);
+        tile_px_fwd(t, q0 < t.npx ? q0 : 0, tb, ty, tx);
         const int b = bcur + tb, oy = y0 + ty, ox = x0 + tx;
         const bool ok = n_out < a.N && q0 < t.npx && b < a.B && oy < a.OH;
         const int step = a.ox_mul * a.y_pix_pitch;
@@ -418,7 +426,7 @@ patch_fwd(const PatchFwdArgs a) {
         for (int i = 0; i < PT; ++i) {
             const int q = q0 + i;
             int tb, ty, tx;
-            tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
+            tile_px_fwd(t, q < t.npx ? q : 0, tb, ty, tx);
             const int b = bcur + tb, oy = y0 + ty, ox = x0 + tx;
             const bool ok = n_out < a.N && q < t.npx && b < a.B && oy < a.OH && ox < a.OW;
             yo[i] = ok ? tb * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
@@ -451,7 +459,7 @@ patch_fwd(const PatchFwdArgs a) {
         const float* cb = nullptr;
         if (per_pixel) {
             int tb, ty, tx;
-            tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+            tile_px_fwd(t, ql < t.npx ? ql : 0, tb, ty, tx);
             const int b = bcur + tb;
             if (ql < t.npx && b < a.B) cb = a.cbias + (size_t)a.labels[b] * a.N;
         }
