@@ -217,10 +217,13 @@ def cpu_baseline(P, y, z, n_stage=4, seconds_budget=14.0):
 
 def load_traffic(config, family):
     """Memory-side bytes per launch of a kernel family from the newest counter file under profiles/ for this
-    configuration (tools/profile_round.sh writes profiles/<tag>_hbm_traffic_<config>.json), or None."""
+    configuration (profiles/<tag>_hbm_traffic_<config>.json from tools/profile_round.sh), or None."""
     import glob
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    paths = sorted(glob.glob(os.path.join(here, "*hbm_traffic_%s.json" % config)), key=os.path.getmtime)
+    # newest = last by name (round3_b_... after round3_a_... after the unprefixed first file): modification times
+    # do not survive a checkout or a copy of the tree
+    paths = sorted(glob.glob(os.path.join(here, "*hbm_traffic_%s.json" % config)),
+                   key=lambda q: (os.path.basename(q).startswith("round"), os.path.basename(q)))
     for path in reversed(paths):
         with open(path) as f:
             got = json.load(f).get(family.replace("(+reduce)", ""), {}).get("bytes")
