@@ -61,7 +61,8 @@ class KernelTimer:
     """HIP-event brackets around every implicit-GEMM launch, on the stream they are launched on."""
 
     def __init__(self, eng):
-        self.eng, self.records, self.hbm = eng, [], []
+        self.eng, self.records, self.hbm, self.empty = eng, [], [], []
+        self._overhead = None
         self._fwd, self._wgrad, self._bn, self._bn_bwd = eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd
 
     def __enter__(self):
@@ -73,6 +74,7 @@ class KernelTimer:
             self._fwd(g, x, y, bias=bias, **kw)
             b.record()
             self.records.append((self.kernel_name(g, "fwd"), gemm_flops(g), a, b, g))
+            self.empty_pair()
 
         def wgrad(g, x, dy, dy_ld):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -103,6 +105,22 @@ class KernelTimer:
 
         eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd = fwd, wgrad, bn, bn_bwd
         return self
+
+    def empty_pair(self):
+        """Two events with nothing between them, in the same stream of queued work: what a bracket adds to the
+        kernel it times (the second event's packet is processed that much after the kernel ends)."""
+        c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c.record()
+        d.record()
+        self.empty.append((c, d))
+
+    def overhead_s(self):
+        """Median empty-pair time, subtracted from every bracket (rocprofv3's kernel durations have no such term)."""
+        if self._overhead is None:
+            torch.cuda.synchronize()
+            ts = sorted(c.elapsed_time(d) for c, d in self.empty)
+            self._overhead = ts[len(ts) // 2] * 1e-3 if ts else 0.0
+        return self._overhead
 
     def __exit__(self, *exc):
         self.eng._fwd, self.eng._wgrad, self.eng._bn, self.eng._bn_bwd = self._fwd, self._wgrad, self._bn, self._bn_bwd
@@ -141,7 +159,7 @@ class KernelTimer:
             key = (("E." + g.key[8:]) if g.key.startswith("encoder.") else ("D." + g.key[8:]) if g.key.startswith("decoder.") else g.key, name,
                    d.B * d.OH * d.OW, d.N, d.ntaps * d.Cin, d.stride, d.oy_off * 2 + d.ox_off, id(g))
             s = agg.setdefault(key, [fl, 0.0])
-            s[1] += a.elapsed_time(b) * 1e-3 / reps
+            s[1] += max(a.elapsed_time(b) * 1e-3 - self.overhead_s(), 1e-7) / reps
         lines = []
         for (key, name, M, N, K, st, cls, _), (fl, t) in agg.items():
             lines.append("%-28s %-30s M %8d N %5d K %5d s%d c%d  %8.1f us  %7.1f TF" % (
@@ -152,7 +170,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         agg = {}
         for name, fl, a, b, _ in self.records:
-            t = a.elapsed_time(b) * 1e-3
+            t = max(a.elapsed_time(b) * 1e-3 - self.overhead_s(), 1e-7)
             s = agg.setdefault(name, [0.0, 0.0, 0])
             s[0] += fl
             s[1] += t
@@ -282,6 +300,7 @@ def infer_main(args, eng, batches, json_fd, P, y, z, B, n_stage, world):
     roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / t / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / t / 1e12 / peak, 4), "traffic": load_traffic(args.config, name),
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
+                "event_pair_overhead_us": round(kt.overhead_s() * 1e6, 2),
                 "all_gemm_ms_per_step": round(sum(v[1] for v in agg.values()) / 2 * 1e3, 3),
                 "executed_tflop_per_step": round(executed / 1e12, 4),
                 "step_tflops_executed": round(executed / (dt / args.steps) / 1e12, 1),
@@ -469,6 +488,8 @@ def main():
     roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
+                # median of empty event pairs recorded between the launches, already subtracted from every bracket
+                "event_pair_overhead_us": round(kt.overhead_s() * 1e6, 2),
                 "all_gemm_ms_per_step": round(total_gemm_t * 1e3, 3),
                 # FLOPs the step's GEMM launches execute (the gradients of the up-convolutions are taken at low
                 # resolution: a quarter of the multiplications of the reference's formulation for those layers),
