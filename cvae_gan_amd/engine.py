@@ -314,6 +314,8 @@ class Engine:
         if share is not None:        # one optimiser state for all engines of the network
             self.step_dev, self.bc_dev = share.step_dev, share.bc_dev
         self._packed_version = -1
+        self._pack_fork, self._pack_done, self._pack_stream = None, None, None
+        self._split_pack = os.environ.get("CVG_PACK_WHOLE") is None     # A/B: the whole repack in front of the step
 
     # canonical parameters may be written by any engine sharing the arenas or by an outside
     # optimiser; one counter tells every engine when its packed shadows are stale
@@ -651,15 +653,34 @@ class Engine:
             desc.co_launches = n
 
     # ------------------------------------------------------------------ helpers
-    def pack_weights(self, force=False):
+    def pack_weights(self, force=False, early_first=False):
+        """Rebuild the packed shadows if the parameters changed.  early_first (enc_forward): only the layouts of the
+        stem and the first block now; the rest (nearly all of the bytes: an HBM-bound pass) is left to _pack_rest(),
+        which the caller invokes once the stem's launches are enqueued, on another stream beside them, and
+        _pack_wait() before the first launch that reads one of those layouts."""
         if not force and self._packed_version == self._param_version:
             return
         if self._pack_batch is None:
-            self._pack_batch = ops.PackBatch([(g.desc, g.wmap, self.params[g.key], g.w) for g in self._gemms],
-                                             self.device)
-        self._pack_batch.run()
+            early = lambda g: g.key.startswith(EP + "conv.1.") or g.key.startswith(EP + "conv.4.")
+            item = lambda g: (g.desc, g.wmap, self.params[g.key], g.w)
+            first = [item(g) for g in self._gemms if early(g)]
+            rest = [item(g) for g in self._gemms if not early(g)]
+            self._pack_batch = (ops.PackBatch(first, self.device) if first else None,
+                                ops.PackBatch(rest, self.device) if rest else None)
+        if self._pack_batch[0] is not None:
+            self._pack_batch[0].run()
         if self.y > 0:
             ops.label_bias(self.params[EP + "conv.1.weight"], self.enc["cbias"], self.ngf, self.y)
+        self._packed_version = self._param_version
+        if early_first and self.overlap and self._split_pack:
+            self._pack_fork = torch.cuda.Event()
+            self._pack_fork.record()
+            return
+        self._pack_rest_launches()
+
+    def _pack_rest_launches(self):
+        if self._pack_batch[1] is not None:
+            self._pack_batch[1].run()
         if getattr(self, "enc", None) and self.enc.get("bias_h") is not None:
             ops.permute_f32(self.params[EP + "fc.3.bias"], self.enc["bias_h"], self.enc["nz"])
         d = self.dec
@@ -667,7 +688,24 @@ class Engine:
             ops.permute_f32(self.params[DP + "fc.0.bias"], d["bias0"], d["F"])
             ops.permute_f32(self.params[DP + "fc.3.bias"], d["bias3"], d["nout"], d["C0"], 1, self.s * self.s)
             ops.permute_f32(self.params[d["tail_key"] + "bias"], d["tail_bias"], 3)
-        self._packed_version = self._param_version
+
+    def _pack_rest(self):
+        if self._pack_fork is None:
+            return
+        if self._pack_stream is None:
+            self._pack_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._pack_stream):
+            self._pack_stream.wait_event(self._pack_fork)
+            self._pack_rest_launches()
+            self._pack_done = torch.cuda.Event()
+            self._pack_done.record()
+        self._pack_fork = None
+
+    def _pack_wait(self):
+        self._pack_rest()
+        if self._pack_done is not None:
+            torch.cuda.current_stream().wait_event(self._pack_done)
+            self._pack_done = None
 
     def _bn(self, x, res, y, M, C, stats, prefix, partial_rows=0):
         """partial_rows > 0: self.red_ws already holds that many rows of column sums / sums of squares of x
@@ -823,7 +861,7 @@ class Engine:
             # what nn.BatchNorm1d (models/networks.py:188) raises in train mode for one sample
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              "torch.Size([1, %d])" % e["fcd"])
-        self.pack_weights()
+        self.pack_weights(early_first=True)
         if self.y > 0:
             # class indices address the per-class bias table, its gradient rows and the one-hot
             # columns of the decoder input: kept inside [0, y) so that a bad index cannot leave
@@ -836,14 +874,18 @@ class Engine:
         self._conv_bn(e["stem"], e["xpad"], e["s0"], None, e["a0"], B * P * P, ngf, e["st0"], EP + "conv.2",
                       bias=self.params[EP + "conv.1.bias"], cbias=e["cbias"],
                       labels=e["labels"] if self.y > 0 else None)
+        self._pack_rest()                    # the other layouts are repacked beside the stem ...
         xin = e["a0"]
-        for blk in e["blocks"]:
+        for i, blk in enumerate(e["blocks"]):
+            if i == 1:
+                self._pack_wait()            # ... and are first needed here
             p, M, C = blk["prefix"], blk["M"], blk["cin"]
             self._conv_bn(blk["conv1"], xin, blk["c1"], None, blk["b1"], M, C, blk["st1"], p + "res.res.1")
             self._conv_bn(blk["conv2"], blk["b1"], blk["c2"], xin, blk["r"], M, C, blk["st2"], p + "res.res.4")
             self._fwd(blk["down"], blk["r"], blk["out"])
             blk["xin"] = xin
             xin = blk["out"]
+        self._pack_wait()
         self._fwd(e["fc0"], xin, e["f0"], bias=self.params[EP + "fc.0.bias"])
         self._bn(e["f0"], None, e["f1"], B, e["fcd"], e["stf"], EP + "fc.1")
         self._fwd(e["fc3"], e["f1"], e["h"], bias=e["bias_h"] if e["bias_h"] is not None else self.params[EP + "fc.3.bias"])
@@ -984,6 +1026,7 @@ class Engine:
         Returns dec f32 NCHW [B,3,P,P]."""
         d, B, P, s = self.dec, self.B, self.P, self.s
         self.pack_weights()
+        self._pack_wait()
         self._fwd(d["fc0"], zin, d["g0"], bias=d["bias0"])
         ops.lrelu_dropout_fwd(d["g0"], mask if self.training else None, d["g1"], B * d["F8"])
         self._fwd(d["fc3"], d["g1"], d["x0"], bias=d["bias3"])
