@@ -800,7 +800,7 @@ class Engine:
         it changes nothing, at the decoder's up-convolutions ("low") it costs 0.05 ms, at the tail 0.2 ms and at the
         Linear layers ("head", "fc") 0.5 ms: there the side launches are what the join at the end of the decoder's
         pass waits for.  CVG_FORK_SITES lists the groups that use the chain-first order (default "blk")."""
-        if not self.overlap or site not in self._fork_sites:
+        if not self.overlap or not (site in self._fork_sites or site.rstrip("0123456789") in self._fork_sites):
             with self._branch():
                 params()
             chain()
@@ -969,7 +969,7 @@ class Engine:
             else:
                 blk["dgd_group"].run(blk["d_out"], blk["d_r"], gate=blk["r"])
 
-        self._fork(down_dgrad, lambda: self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"]), "down")
+        self._fork(down_dgrad, lambda: self._wgrad(blk["down"], blk["r"], blk["d_out"], blk["cout"]), "down%d" % i)
         self._bn_bwd(blk["d_r"], None, blk["c2"], blk["d_c2"], M, C, blk["st2"], p + "res.res.4", gated=True)
         self._fork(lambda: self._fwd(blk["dg2"][0], blk["d_c2"], blk["d_b1"]),
                    lambda: self._wgrad(blk["conv2"], blk["b1"], blk["d_c2"], C))
@@ -1082,7 +1082,7 @@ class Engine:
                         ops.colsum(up["z"].view(-1)[4 * N:], B * up["h"] * up["h"], N, 9 * N,
                                    self.grads[up["key"] + "bias"], self.red_ws_side)
 
-                self._fork(lambda up=up, d_x=d_x: self._fwd(up["dg_low"], up["z"], d_x), low_params, "low")
+                self._fork(lambda up=up, d_x=d_x: self._fwd(up["dg_low"], up["z"], d_x), low_params, "low%d" % i)
                 continue
             def hires_params(up=up, M=M):
                 self._wgrad(up["fwd"], up["u"], up["d_y"], up["cout"])
