@@ -297,6 +297,29 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+class ArenaExchange:
+    """SUM all-reduce of whole gradient arenas on a communication stream: start(arena) when everything that writes
+    the arena is enqueued on the current stream, finish() before the optimiser.  The adversarial step has three
+    arenas that become final one after the other (discriminator, classifier, CVAE); each travels while the rest
+    of the step runs.  "nccl": the reduction runs on the device; any other backend reduces a host copy (rehearsals)."""
+
+    def __init__(self, device, group=None):
+        self.group = group
+        self.stream = torch.cuda.Stream(device=device)
+
+    def start(self, arena):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            allreduce_sum_(arena, self.group)
+
+    def finish(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 def env_world():
     """(rank, local_rank, world_size) from the launcher's environment (torchrun); (0, 0, 1) without one."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),

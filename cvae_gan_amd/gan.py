@@ -23,7 +23,9 @@ One step, for real images x with labels c, eps for the sampler and prior draws (
 E and G minimise L_VAE + lam_gd L_GD + lam_gc L_GC + lam_pd L_PD + lam_pc L_PC with D and C held constant;
 the image gradients of the matching losses reach x_p and x_f (and, through the joint BatchNorm statistics,
 each other).  Data parallel: every loss gradient takes loss_scale = 1 / world and the three gradient
-arenas are summed over the ranks (all_reduce_grads); BatchNorm statistics and class centres stay per replica.
+arenas are summed over the ranks, each on a communication stream as soon as it is final (the discriminator's
+after its own backward pass, the classifier's after its own, the CVAE's at the end: ddp.ArenaExchange);
+BatchNorm statistics and class centres stay per replica.
 """
 from collections import OrderedDict
 
@@ -93,59 +95,86 @@ class CVAEGAN:
         self.labels_p = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.centres = torch.zeros(y_dim, features, dtype=torch.float32, device=dev)      # class centres of f_C over real images
         self.centres_seen = torch.zeros(y_dim, dtype=torch.int32, device=dev)
+        self._exchange = None
 
-    def forward_backward(self, x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0):
+    def forward_backward(self, x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0, on_final=None):
         """x f32 NCHW [B,3,P,P]; labels int32 [B]; eps, z_p f32 [B,z]; y_p one-hot f32 [B,y].  The two
         dropout masks are the ones last set on self.vae / self.gen2.  Gradients (times loss_scale) land in
         the four networks' arenas; losses: self.vae.losses[0:2] = KL, LL; self.D.losses / self.C.losses =
-        [own loss, matching loss, pairwise loss]."""
+        [own loss, matching loss, pairwise loss].
+        on_final(arena): called as soon as a network's parameter gradients are final (the discriminator's, then
+        the classifier's, then the CVAE's), with everything that produces them enqueued on the current stream: a
+        data-parallel driver starts that arena's exchange there, beside the rest of the step."""
+        out = None
+        for piece, arena in zip(self.pieces(x, labels, eps, z_p, y_p, batch_size, loss_scale),
+                                (self.D.trunk.g_arena, self.C.trunk.g_arena, self.vae.g_arena)):
+            out = piece()
+            if on_final is not None:
+                on_final(arena)
+        return out
+
+    def pieces(self, x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0):
+        """forward_backward() as three consecutive callables (a driver that captures each into a graph of its own
+        and exchanges gradients between them): after the first the discriminator's parameter gradients are final,
+        after the second the classifier's, after the third (which returns (reconstruction, sample)) the CVAE's."""
         A, G2, D, C, B = self.vae, self.gen2, self.D, self.C, self.B
         ls = float(loss_scale)
-        # ---- E, G forward
-        h = A.enc_forward(x, labels)
-        zin = A.sample(h, eps, batch_size)
-        dec_f = A.dec_forward(zin, A.dec["mask"])
-        dec_p = G2.dec_forward(G2.set_decoder_input(z_p, y_p), G2.dec["mask"])
-        self.x3[:B].copy_(x)
-        self.x3[B:2 * B].copy_(dec_f)
-        self.x3[2 * B:].copy_(dec_p)
-        self.labels_dev[:B].copy_(A.enc["labels"])        # the copy enc_forward made: inside [0, y)
-        self.labels_p.copy_(y_p.argmax(dim=1))
-        # ---- critics: own losses (parameter gradients), then the matching losses (image gradients)
         M, F = 3 * B, D.F
-        hD = D.forward(self.x3)
-        ops.gan_d_head(hD, F, D.params["head.weight"], D.params["head.bias"], M, F, B, ls, D.grads["head.weight"],
-                       D.grads["head.bias"], D.losses[0:1], D.dh_own, D.ws)
-        ops.gan_feature_match(hD, F, M, F, 0, B, 2 * B, M, self.lam_gd * ls, D.losses[1:2], D.dh_gen)
-        ops.gan_pair_feature_match(hD, F, F, 0, B, B, self.lam_pd * ls, D.losses[2:3], D.dh_gen, D.ws)
-        D.backward_own()
-        dimg_d = D.backward_generator()
-        hC = C.forward(self.x3)
-        ops.gan_c_head(hC, F, C.params["head.weight"], C.params["head.bias"], self.labels_dev, M, F, self.y, B, ls,
-                       C.grads["head.weight"], C.grads["head.bias"], C.losses[0:1], C.dh_own, C.ws)
-        if self.per_class:
-            C.dh_gen.zero_()
-            ops.gan_class_feature_match(hC, F, F, self.labels_dev, self.labels_p, 0, B, 2 * B, M, self.y, self.centres,
-                                        self.centres_seen, self.centre_momentum, self.lam_gc * ls, C.losses[1:2],
-                                        C.dh_gen, C.ws)
-        else:
-            ops.gan_feature_match(hC, F, M, F, 0, B, 2 * B, M, self.lam_gc * ls, C.losses[1:2], C.dh_gen)
-        ops.gan_pair_feature_match(hC, F, F, 0, B, B, self.lam_pc * ls, C.losses[2:3], C.dh_gen, C.ws)
-        C.backward_own()
-        dimg_c = C.backward_generator()
-        # ---- generator / encoder backward
-        d = A.dec
-        ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, ls, A.red_rows)
-        ops.axpy(d["d_dec"], dimg_d[B:2 * B], 1.0)
-        ops.axpy(d["d_dec"], dimg_c[B:2 * B], 1.0)
-        G2.dec["d_dec"].copy_(dimg_d[2 * B:])
-        ops.axpy(G2.dec["d_dec"], dimg_c[2 * B:], 1.0)
-        dzin = A.dec_backward(d["d_dec"], d["mask"])
-        A.sample_backward(dzin, eps, None, None, ls, batch_size)
-        A.enc_backward(A.enc["dh"])
-        G2.dec_backward(G2.dec["d_dec"], G2.dec["mask"])
-        ops.axpy(A.g_arena, G2.g_arena, 1.0)
-        return dec_f, dec_p
+        st = {}
+
+        def discriminator():
+            # ---- E, G forward
+            h = A.enc_forward(x, labels)
+            zin = A.sample(h, eps, batch_size)
+            st["dec_f"] = dec_f = A.dec_forward(zin, A.dec["mask"])
+            st["dec_p"] = dec_p = G2.dec_forward(G2.set_decoder_input(z_p, y_p), G2.dec["mask"])
+            self.x3[:B].copy_(x)
+            self.x3[B:2 * B].copy_(dec_f)
+            self.x3[2 * B:].copy_(dec_p)
+            self.labels_dev[:B].copy_(A.enc["labels"])        # the copy enc_forward made: inside [0, y)
+            self.labels_p.copy_(y_p.argmax(dim=1))
+            # ---- the discriminator's own loss (parameter gradients) and matching losses (their image gradient
+            # comes from backward_generator() in the next piece, with the parameters held constant)
+            hD = D.forward(self.x3)
+            ops.gan_d_head(hD, F, D.params["head.weight"], D.params["head.bias"], M, F, B, ls, D.grads["head.weight"],
+                           D.grads["head.bias"], D.losses[0:1], D.dh_own, D.ws)
+            ops.gan_feature_match(hD, F, M, F, 0, B, 2 * B, M, self.lam_gd * ls, D.losses[1:2], D.dh_gen)
+            ops.gan_pair_feature_match(hD, F, F, 0, B, B, self.lam_pd * ls, D.losses[2:3], D.dh_gen, D.ws)
+            D.backward_own()
+
+        def classifier():
+            st["dimg_d"] = D.backward_generator()
+            hC = C.forward(self.x3)
+            ops.gan_c_head(hC, F, C.params["head.weight"], C.params["head.bias"], self.labels_dev, M, F, self.y, B, ls,
+                           C.grads["head.weight"], C.grads["head.bias"], C.losses[0:1], C.dh_own, C.ws)
+            if self.per_class:
+                C.dh_gen.zero_()
+                ops.gan_class_feature_match(hC, F, F, self.labels_dev, self.labels_p, 0, B, 2 * B, M, self.y, self.centres,
+                                            self.centres_seen, self.centre_momentum, self.lam_gc * ls, C.losses[1:2],
+                                            C.dh_gen, C.ws)
+            else:
+                ops.gan_feature_match(hC, F, M, F, 0, B, 2 * B, M, self.lam_gc * ls, C.losses[1:2], C.dh_gen)
+            ops.gan_pair_feature_match(hC, F, F, 0, B, B, self.lam_pc * ls, C.losses[2:3], C.dh_gen, C.ws)
+            C.backward_own()
+
+        def generator():
+            dimg_d, dec_f = st["dimg_d"], st["dec_f"]
+            dimg_c = C.backward_generator()
+            # ---- generator / encoder backward
+            d = A.dec
+            ops.mse_fwd_bwd(dec_f, x, d["d_dec"], A.losses[1:2], dec_f.numel(), batch_size, ls, A.red_rows)
+            ops.axpy(d["d_dec"], dimg_d[B:2 * B], 1.0)
+            ops.axpy(d["d_dec"], dimg_c[B:2 * B], 1.0)
+            G2.dec["d_dec"].copy_(dimg_d[2 * B:])
+            ops.axpy(G2.dec["d_dec"], dimg_c[2 * B:], 1.0)
+            dzin = A.dec_backward(d["d_dec"], d["mask"])
+            A.sample_backward(dzin, eps, None, None, ls, batch_size)
+            A.enc_backward(A.enc["dh"])
+            G2.dec_backward(G2.dec["d_dec"], G2.dec["mask"])
+            ops.axpy(A.g_arena, G2.g_arena, 1.0)
+            return dec_f, st["dec_p"]
+
+        return discriminator, classifier, generator
 
     def all_reduce_grads(self):
         """Data parallel: sum the gradient arenas of the CVAE, the discriminator and the classifier over
@@ -164,10 +193,20 @@ class CVAEGAN:
         self.D.adamw_step(lr)
         self.C.adamw_step(lr)
 
+    def exchange(self):
+        """The stream-ordered exchange of the three gradient arenas (ddp.ArenaExchange), created on first use."""
+        if self._exchange is None:
+            from . import ddp
+            self._exchange = ddp.ArenaExchange(self.vae.device)
+        return self._exchange
+
     def train_step(self, x, labels, eps, z_p, y_p, batch_size, lr, world=1):
-        out = self.forward_backward(x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0 / world)
         if world > 1:
-            self.all_reduce_grads()
+            ex = self.exchange()         # each arena travels as soon as it is final, beside the rest of the step
+            out = self.forward_backward(x, labels, eps, z_p, y_p, batch_size, loss_scale=1.0 / world, on_final=ex.start)
+            ex.finish()
+        else:
+            out = self.forward_backward(x, labels, eps, z_p, y_p, batch_size)
         self.adamw_step(lr)
         return out
 
@@ -183,8 +222,8 @@ class CVAEGAN:
 class GraphedGanStep:
     """The adversarial step (dropout draws, the four networks' forward and backward passes, three AdamW
     updates, weight repacks) replayed from HIP graphs on static input buffers.  One replica: ONE graph.
-    Several replicas: [forward + backward] -> all-reduce of the three gradient arenas -> [AdamW], i.e. two
-    graphs with the exchange between them.  Captured in thread-local mode, like ddp.GraphedStep."""
+    Several replicas: one graph per piece of the step (CVAEGAN.pieces), each followed by the all-reduce of the
+    arena it completed on a communication stream while the next piece runs, then [AdamW].  Captured in thread-local mode, like ddp.GraphedStep."""
 
     def __init__(self, net, batch_size, lr, world=1):
         self.net, self.batch_size, self.lr, self.world = net, float(batch_size), lr, world
@@ -221,11 +260,21 @@ class GraphedGanStep:
                 net.adamw_step(self.lr)
             self.graphs = [g]
         else:
-            gs = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+            # one graph per piece of the step, so that each network's arena can travel while the next piece runs
+            gs = [torch.cuda.CUDAGraph() for _ in range(4)]
             mode["pool"] = torch.cuda.graph_pool_handle()
+            pieces = net.pieces(gx, gl, ge, gz, gy, self.batch_size, loss_scale=1.0 / self.world)
             with torch.cuda.graph(gs[0], **mode):
-                fwd_bwd()
+                net.vae.random_mask()
+                net.gen2.random_mask()
+                for e in self._engines():
+                    e._packed_version = -1
+                pieces[0]()
             with torch.cuda.graph(gs[1], **mode):
+                pieces[1]()
+            with torch.cuda.graph(gs[2], **mode):
+                self.out = pieces[2]()
+            with torch.cuda.graph(gs[3], **mode):
                 net.adamw_step(self.lr)
             self.graphs = gs
         for e, c in zip(owners, saved):
@@ -237,10 +286,15 @@ class GraphedGanStep:
         for dst, src in zip(self.inputs, (x, labels, eps, z_p, y_p)):
             dst.copy_(src)
         net = self.net
-        self.graphs[0].replay()
-        if self.world > 1:
-            net.all_reduce_grads()
-            self.graphs[1].replay()
+        if self.world == 1:
+            self.graphs[0].replay()
+        else:
+            ex = net.exchange()
+            for g, arena in zip(self.graphs[:3], (net.D.trunk.g_arena, net.C.trunk.g_arena, net.vae.g_arena)):
+                g.replay()
+                ex.start(arena)
+            ex.finish()
+            self.graphs[3].replay()
         for e in (net.vae, net.D.trunk, net.C.trunk):
             e.step_count += 1
             e.params_changed()

@@ -96,14 +96,16 @@ def test_trainer_two_ranks_share_one_gpu(tmp_path):
 
 
 def test_gan_trainer_two_ranks(tmp_path):
-    """--gan_type CVAEGAN under two ranks: the CVAE's, the discriminator's and the classifier's gradient
-    arenas are summed over the ranks after backward; rank 0 writes all four checkpoints."""
+    """--gan_type CVAEGAN under two ranks: the discriminator's, the classifier's and the CVAE's gradient arenas
+    are summed over the ranks, each as soon as it is final; two eager steps, then three from the four graphs of
+    gan.GraphedGanStep with the exchanges between them; rank 0 writes all four checkpoints."""
     out = _run_ranks(["-m", "cvae_gan_amd.starter", "--dataset", "Synth", "--data_dir", str(tmp_path / "none"),
-                      "--data_size", "64", "--pix_dim", "32", "--y_dim", "4", "--z_dim", "8", "--batch_size", "16",
-                      "--epoch", "1", "--max_iters", "2", "--lrG", "1e-3", "--worker", "0", "--gpus", "0",
+                      "--data_size", "128", "--pix_dim", "32", "--y_dim", "4", "--z_dim", "8", "--batch_size", "16",
+                      "--epoch", "1", "--max_iters", "5", "--lrG", "1e-3", "--worker", "0", "--gpus", "0",
                       "--gan_type", "CVAEGAN", "--save_dir", str(tmp_path / "ck"), "--result_dir", str(tmp_path / "res")], 2,
                      extra_env={"CVG_DDP_BACKEND": "gloo", "CVG_DDP_SHARE_GPU": "1"})
     assert "Training finish" in out[0]
+    assert "capture of the adversarial step failed" not in out[0]
     d = os.path.join(str(tmp_path / "ck"), "VAE_data_Synth_pix_32_batch_16_embed_8")
     for name in ("encoder", "decoder", "discriminator", "classifier"):
         sd = torch.load(os.path.join(d, "Synth_%s.pkl" % name), weights_only=True)
