@@ -1291,6 +1291,29 @@ __global__ void tail_sum_tanh(const T* __restrict__ v, const float* __restrict__
 #pragma unroll
     for (int c = 0; c < 3; ++c) dec[((size_t)b * 3 + c) * PP + hw] = tanhf(s[c]);
 }
+// Input gradient of a 7x7 convolution with 3 (stored as 4) input channels from per-column partials: v[b][y][j][kw*4 + c]
+// holds, for input column j of the incoming gradient and kernel column kw, the sum over the 7 kernel rows and all
+// output channels; out[b][y][x][c] = sum_kw v[b][y][x - kw][kw*4 + c] over the columns that exist (0 <= x - kw < P),
+// x in [0, P + 6): the gradient with respect to the padded image, as 8-channel pixels (channels 3.. zero).
+template <typename T>
+__global__ void window_col_sum(const T* __restrict__ v, T* __restrict__ out, int B, int rows, int P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*rows*(P+6) pixels
+    const int W = P + 6;
+    if (i >= (int64_t)B * rows * W) return;
+    const int x = (int)(i % W);
+    const int64_t by = i / W;                                            // b * rows + y
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+        const int j = x - kw;
+        if (j < 0 || j >= P) continue;
+        float t[4];
+        load4<T>(v + ((size_t)by * P + j) * 32 + kw * 4, t);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[c] += t[c];
+    }
+    store8<T>(out + (size_t)i * 8, s);
+}
 template <typename T>
 __global__ void tanh_bwd(const float* __restrict__ d_dec, const float* __restrict__ dec, T* __restrict__ dpre,
                          T* __restrict__ win, int B, int PP, int P) {
@@ -1758,6 +1781,13 @@ int cvg_tail_sum_tanh(const void* v, const float* bias, void* pre, float* dec, i
     CVG_CHECK(v && bias && pre && dec && B > 0 && P > 0, "tail_sum_tanh: bad args");
     DISPATCH(dtype, tail_sum_tanh<T><<<grid1((int64_t)B * P * P), 256, 0, (hipStream_t)stream>>>((const T*)v, bias, (T*)pre,
                                                                                                 dec, B, P));
+    CVG_LAUNCH_CHECK();
+    return 0;
+}
+int cvg_window_col_sum(const void* v, void* out, int32_t dtype, int32_t B, int32_t rows, int32_t P, cvg_stream stream) {
+    CVG_CHECK(v && out && B > 0 && rows > 0 && P > 0, "window_col_sum: bad args");
+    DISPATCH(dtype, window_col_sum<T><<<grid1((int64_t)B * rows * (P + 6)), 256, 0, (hipStream_t)stream>>>((const T*)v, (T*)out,
+                                                                                                        B, rows, P));
     CVG_LAUNCH_CHECK();
     return 0;
 }

@@ -450,9 +450,19 @@ class Engine:
         if self.stem_input_grad:
             # gradient w.r.t. the reflection-padded image = full correlation of d_s0 with the
             # flipped kernel (zero padding 6), channels 3.. dropped; folded back by cvg_reflect_fold
-            e["stem_dg"] = _Gemm(self, _desc(T, B, P, P, ngf, P + 6, P + 6, 8, 7, 49, off=(-6, -6)),
-                                 _wmap(1, 49, 0, ngf, 1, (3 + self.y) * 49, 3, ngf, 49, tap_mode=1),
-                                 EP + "conv.1.weight")
+            e["stem_dg"], e["stem_dg_v"] = None, None
+            if ngf % 32 == 0 and os.environ.get("CVG_STEM_DGRAD_49") is None:
+                # as 7 row taps with (kernel column, input channel) as 32 "output channels", finished by a 7-column
+                # sum (cvg_window_col_sum): a seventh of the multiplications of the 49-tap form below, whose GEMM has
+                # 3 real output rows out of 32
+                e["stem_dg_v"] = _Gemm(self, _desc(T, B, P, P, ngf, P + 6, P, 32, 1, 7, off=(-6, 0)),
+                                       _wmap(4, 1, 49, ngf, 7, (3 + self.y) * 49, 28, ngf, 7, tap_mode=1, nr_valid=3),
+                                       EP + "conv.1.weight")
+                e["v_dg"] = self._t(B * (P + 6) * P, 32)
+            else:
+                e["stem_dg"] = _Gemm(self, _desc(T, B, P, P, ngf, P + 6, P + 6, 8, 7, 49, off=(-6, -6)),
+                                     _wmap(1, 49, 0, ngf, 1, (3 + self.y) * 49, 3, ngf, 49, tap_mode=1),
+                                     EP + "conv.1.weight")
             e["d_xp"] = self._t(B * (P + 6) * (P + 6), 8)
             e["d_x8"] = self._t(B * P * P, 8)
             e["d_img"] = self._f(B, 3, P, P)
@@ -991,7 +1001,11 @@ class Engine:
                                    self.grads[EP + "conv.1.bias"], self.red_ws_side[WS_HEADER:])
         d_img = None
         if input_grad:
-            self._fwd(e["stem_dg"], e["d_s0"], e["d_xp"])
+            if e["stem_dg_v"] is not None:
+                self._fwd(e["stem_dg_v"], e["d_s0"], e["v_dg"])
+                ops.window_col_sum(e["v_dg"], e["d_xp"], B, P + 6, P)
+            else:
+                self._fwd(e["stem_dg"], e["d_s0"], e["d_xp"])
             ops.reflect_fold(e["d_xp"], e["d_x8"], B, P, P, 8, 3)
             ops.nhwc_to_nchw(e["d_x8"], e["d_img"], B, P * P, 3, 8)
             d_img = e["d_img"]

@@ -233,6 +233,10 @@ def image_u8_to_f32(hwc_u8, nchw_f32, B, P):
     check(lib.cvg_image_u8_to_f32(ptr(hwc_u8), ptr(nchw_f32), B, P, stream()))
 
 
+def window_col_sum(v, out, B, rows, P):
+    check(lib.cvg_window_col_sum(ptr(v), ptr(out), dt(v), B, rows, P, stream()))
+
+
 def tail_sum_tanh(v, bias, pre, dec, B, P):
     check(lib.cvg_tail_sum_tanh(ptr(v), ptr(bias), ptr(pre), ptr(dec), dt(v), B, P, stream()))
 

@@ -365,6 +365,13 @@ int cvg_tail_sum_tanh(const void* v, const float* bias, void* pre, float* dec, i
                       int32_t B, int32_t P, cvg_stream s);
 int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, void* dpre_win, int32_t dtype,
                  int32_t B, int32_t P, cvg_stream s);
+/* Gradient with respect to the padded 3-channel input of a 7x7 convolution (the stem, nn.Conv2d(3 + y, 64, 7) after
+ * ReflectionPad2d(3), networks.py:168-170, as a critic's trunk sees it) finished from column partials: v [B][rows][P][32]
+ * (dtype) holds, for column j of the incoming gradient and kernel column kw, the sum over the 7 kernel rows and all
+ * output channels at v[..][j][kw*4 + c] (a 7-row-tap convolution with 32 "output channels", a seventh of the
+ * multiplications of the 49-tap form with 3 real output rows of 32);
+ * out[b][y][x][c] = sum_kw v[b][y][x - kw][kw*4 + c], x in [0, P + 6) -> out [B*rows*(P+6)][8] (dtype), channels 3.. zero. */
+int cvg_window_col_sum(const void* v, void* out, int32_t dtype, int32_t B, int32_t rows, int32_t P, cvg_stream s);
 /* Reconstruction loss of models/cvae.py:139: ll = 50 * mean((dec - x)^2) / batch_size,
  * and d_dec = scale * 100 * (dec - x) / (numel * batch_size).                       */
 int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, int64_t numel,
