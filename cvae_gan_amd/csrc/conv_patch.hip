@@ -598,6 +598,191 @@ __global__ void patch_pack(const float* __restrict__ canonical, T* __restrict__ 
 }
 
 // ======================================================================================
+// forward, seven row taps over 8-pixel x 4-channel windows (K = 224): the stem and the tail's input gradient
+// ======================================================================================
+// These layers have so little to multiply per output tile (56 MFMAs per wave) that patch_fwd spends two thirds of a
+// tile's time outside its main loop (address arithmetic, first patch, weight ring, then the epilogue) and stages every
+// 64-byte window separately although neighbouring windows share 56 of their bytes.  Here a workgroup stays resident
+// and walks over tiles: its weights (14 fragments per wave) live in registers for the whole launch, the tile's RAW
+// pixels ((TH + 6) x (TW + 7) pixels of 8 bytes, a seventh of the window bytes) are staged once, double-buffered,
+// with the next tile's pixels requested before the current tile is multiplied, and a window's fragment is two
+// 8-byte LDS reads at 8-byte alignment.  Epilogue as patch_fwd's (bias, class bias, LDS-staged row stores); the sums
+// are taken in the same order, so the results are bit-identical to patch_fwd's.
+struct LowKArgs {
+    const void* x; const void* wf; void* y;
+    const float* bias; const float* cbias; const int* labels;
+    int B, H, W, x_img_pitch, x_row_pitch;     // W: input pixels (of 4 channels) per row
+    int off_y, off_x;
+    int OH, OW, N;
+    int y_img_pitch, y_row_pitch, y_pix_pitch;
+    int tiles_y, ntiles;                        // tiles per image group; tiles in all
+    int RP, raw_px, raw_bytes;                  // raw row pitch in pixels; staged pixels per tile; bytes of one raw buffer
+    TileGeom t;                                 // PH = TH + 6, PW = TW + 7 (raw pixels)
+    FastDiv div_tiles;                          // by tiles per image group
+};
+
+__global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
+    constexpr int NIT = 4;                      // raw 8-byte pixels per thread (<= 1024 per tile)
+    constexpr int OP = 64 * 2 + 16;             // staged output row pitch: 64 channels of bf16 + padding
+    constexpr int FRAG = 64 * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TileGeom& t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * 64;
+
+    // ---- this wave's weights: 32 rows x 224, resident
+    bf16x8 wr[7][2];
+    {
+        const bf16* wp = (const bf16*)a.wf + ((size_t)(n0 / 32 + wn) * 14) * FRAG + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) wr[j][sub] = *(const bf16x8*)(wp + (size_t)(j * 2 + sub) * FRAG);
+    }
+    float bpre[4][4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + wn * 32 + 8 * g4 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bpre[g4][j] = (a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
+    }
+
+    // ---- raw pixels of this thread: position inside the patch (the same for every tile)
+    int rpy[NIT], rpx[NIT], rtb[NIT], rso[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + 256 * i;
+        rtb[i] = -1; rpy[i] = rpx[i] = 0; rso[i] = a.raw_bytes - 8;      // absent: a slot nothing reads
+        if (idx < a.raw_px) {
+            const int tb = fdiv(idx, t.div_phw);
+            const int r = idx - tb * (t.PH * t.PW);
+            const int py = fdiv(r, t.div_pw);
+            rtb[i] = tb; rpy[i] = py; rpx[i] = r - py * t.PW;
+            rso[i] = ((tb * t.PH + py) * a.RP + rpx[i]) * 8;
+        }
+    }
+    unsigned long long rv[NIT];
+    auto tile_origin = [&](int tile, int& b0, int& y0, int& x0) {
+        const int g = fdiv(tile, a.div_tiles);
+        const int r = tile - g * (a.tiles_y * t.tiles_x);
+        const int tyi = fdiv(r, t.div_tx);
+        b0 = g * t.TB; y0 = tyi * t.TH; x0 = (r - tyi * t.tiles_x) * t.TW;
+    };
+    auto load_raw = [&](int tile) {
+        int b0, y0, x0;
+        tile_origin(tile, b0, y0, x0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int b = b0 + rtb[i], iy = y0 + rpy[i] + a.off_y, ix = x0 + rpx[i] + a.off_x;
+            const bool ok = rtb[i] >= 0 && b < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const size_t off = ok ? (size_t)b * a.x_img_pitch + (size_t)iy * a.x_row_pitch + (size_t)ix * 4 : 0;
+            const unsigned long long v = *(const unsigned long long*)((const bf16*)a.x + off);
+            rv[i] = ok ? v : 0ull;
+        }
+    };
+
+    // ---- this lane's pixel columns inside the raw patch, and the second half's thread mapping (fixed per launch)
+    int abase[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        int q = wm * 128 + mi * 32 + l31;
+        if (q >= t.npx) q = 0;
+        int tb, ty, tx;
+        tile_px(t, q, tb, ty, tx);
+        abase[mi] = ((tb * t.PH + ty) * a.RP + tx + 2 * h) * 8;
+    }
+    constexpr int PPR = 8, PT = 8;               // 16-byte pieces per staged row; pixels per thread in the store phase
+    const int pc = tid % PPR, q0 = (tid / PPR) * PT;
+    const int n_out = n0 + pc * 8;
+    const bool whole = n_out + 8 <= a.N;
+    char* const stg = smem + 2 * a.raw_bytes;
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) load_raw(tile);
+    int bsel = 0;
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        char* buf = smem + bsel * a.raw_bytes;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) *(unsigned long long*)(buf + rso[i]) = rv[i];
+        __syncthreads();
+        int b0, y0, x0;
+        tile_origin(tile, b0, y0, x0);
+        const int next = tile + gridDim.x;
+        load_raw(next < a.ntiles ? next : tile);             // (past the end: the same tile again, unused)
+        // class bias rows of this lane's pixels: the label now, the row in the epilogue
+        int lab[4];
+        if (a.cbias) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int ql = wm * 128 + mi * 32 + l31;
+                int tb, ty, tx;
+                tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+                lab[mi] = (ql < t.npx && b0 + tb < a.B) ? a.labels[b0 + tb] : -1;
+            }
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                bf16x8 xf[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const char* src = buf + abase[mi] + (j * a.RP + sub * 4) * 8;
+                    const unsigned long long lo = *(const unsigned long long*)src, hi = *(const unsigned long long*)(src + 8);
+                    const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+                    xf[mi] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma32(acc[mi], wr[j][sub], xf[mi]);
+            }
+        }
+        // ---- epilogue: bias, class bias, through LDS, whole pixel rows out
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ql = wm * 128 + mi * 32 + l31;
+            const float* cb = (a.cbias && lab[mi] >= 0) ? a.cbias + (size_t)lab[mi] * a.N : nullptr;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nl = wn * 32 + 8 * g4 + 4 * h, n = n0 + nl;
+                float v[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][4 * g4 + jj];
+                if (n < a.N) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[jj] += bpre[g4][jj];
+                    if (cb) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[jj] += cb[n + jj];
+                    }
+                }
+                store4<bf16>((bf16*)(stg + ql * OP) + nl, v);
+            }
+        }
+        __syncthreads();
+        bf16* __restrict__ yp = (bf16*)a.y + (size_t)b0 * a.y_img_pitch;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int q = q0 + i;
+            int tb, ty, tx;
+            tile_px(t, q < t.npx ? q : 0, tb, ty, tx);
+            const int b = b0 + tb, oy = y0 + ty, ox = x0 + tx;
+            if (!(n_out < a.N && q < t.npx && b < a.B && oy < a.OH && ox < a.OW)) continue;
+            const u32x4 v = *(const u32x4*)(stg + q * OP + pc * 16);
+            bf16* dst = yp + (size_t)tb * a.y_img_pitch + (size_t)oy * a.y_row_pitch + (size_t)ox * a.y_pix_pitch + n_out;
+            if (whole) *(u32x4*)dst = v;
+            else *(unsigned long long*)dst = ((unsigned long long)v[1] << 32) | v[0];
+        }
+        bsel ^= 1;
+    }
+}
+
+// ======================================================================================
 // weight gradient
 // ======================================================================================
 struct PatchWgradArgs {
@@ -1511,9 +1696,55 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     p.ok = 1;
 }
 
+// The resident seven-row-tap kernel takes the launch when the descriptor is one of its layers (bf16, 8-pixel x
+// 4-channel windows, plain output, nothing but bias terms in the epilogue).  Returns 1 if it did, 0 if not, -1 on error.
+static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
+                        const float* bias, const float* cbias, const int32_t* labels, hipStream_t s) {
+    if (cvg_switches().no_lowk) return 0;
+    if (d->dtype != CVG_BF16 || p.KW != 1 || p.T != 7 || d->Cin != 32 || d->x_pix_pitch != 4 || p.nchunks != 1) return 0;
+    if (d->pad_mode != CVG_PAD_ZERO || d->oy_mul != 1 || d->ox_mul != 1 || d->oy_off != 0 || d->ox_off != 0) return 0;
+    if (d->N > 65535 * 64 || d->N % 4 != 0 || d->y_pix_pitch % 8 != 0 || d->y_row_pitch % 8 != 0 || d->y_img_pitch % 8 != 0) return 0;
+    if (d->x_row_pitch % 4 != 0 || d->x_img_pitch % 4 != 0) return 0;
+    // a tiling of its own: 256 output pixels per tile, fewest tiles, then fewest raw pixels ((TH + 6) x (TW + 7) per image)
+    int TB, TH, TW;
+    // (one image per tile where an image has 256 pixels or more: tiles of several small pieces of several images
+    // save a few tiles and cost more raw pixels, LDS and address arithmetic)
+    const int b_tile = (int64_t)d->OH * d->OW >= 256 ? 1 : d->B;
+    if (!choose_tile(b_tile, d->OH, d->OW, 7, 8, 256, 1024, TB, TH, TW) || !offsets_fit(d, TB)) return 0;
+    const int tiles_y = ceil_div(d->OH, TH), tiles_x = ceil_div(d->OW, TW), groups = ceil_div(d->B, TB);
+    LowKArgs a;
+    a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
+    a.off_y = d->off_y; a.off_x = d->off_x; a.OH = d->OH; a.OW = d->OW; a.N = d->N;
+    a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
+    fill_tile(a.t, TB, TH, TW, 7, 8, tiles_x);                // PH = TH + 6, PW = TW + 7 raw pixels
+    a.tiles_y = tiles_y;
+    const int64_t ntiles = (int64_t)tiles_y * tiles_x * groups;
+    if (ntiles >= (1ll << 30)) return 0;
+    a.ntiles = (int)ntiles;
+    a.div_tiles = make_fastdiv(tiles_y * tiles_x);
+    // raw rows TW + 32 pixels apart: the tile rows that one 32-lane read group covers follow each other in bank
+    // space (16-pixel rows 384 bytes apart: two of them fill the 64 banks once)
+    a.RP = TW + 32;
+    a.raw_px = TB * a.t.PH * a.t.PW;
+    if (a.raw_px > 1024) return 0;
+    a.raw_bytes = (TB * a.t.PH * a.RP * 8 + 8 + 255) & ~255;
+    const size_t lds = 2 * (size_t)a.raw_bytes + 256 * (64 * 2 + 16);
+    if (lds > 72 * 1024) return 0;                             // two workgroups per CU
+    if (set_lds(lowk_fwd, lds)) return -1;
+    const int wgs = a.ntiles < 512 ? a.ntiles : 512;           // two resident workgroups per CU walk over the tiles
+    lowk_fwd<<<dim3(wgs, ceil_div(d->N, 64)), 256, lds, s>>>(a);
+    if (hipGetLastError() != hipSuccess) CVG_FAIL("lowk_fwd launch failed");
+    return 1;
+}
+
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
                      const void* gate, hipStream_t s, const float* scale, const float* shift, int act, float* stat_ws) {
+    if (!res && !gate && !scale && !stat_ws) {
+        const int got = lowk_fwd_try(d, p, x, w, y, bias, cbias, labels, s);
+        if (got) return got < 0 ? -1 : 0;
+    }
     PatchFwdArgs a;
     a.scale = scale; a.shift = shift; a.act = act; a.stat_ws = stat_ws;
     const int es = d->dtype == CVG_BF16 ? 2 : 4;

@@ -504,3 +504,53 @@ def test_conv_epilogue_statistics(dtype, B, H, cin, cout):
     d2 = _desc(dtype, B, H, H, cin, H // 2, H // 2, cout, 3, 9, stride=2, off=(-1, -1)) if H % 2 == 0 else None
     if d2 is not None:
         assert ops.conv_stats_partials(d2) == 0
+
+
+def test_resident_row_tap_kernel_bit_identical():
+    """The stem's shape class (7 row taps over 8-pixel x 4-channel windows, K = 224) runs on a kernel of its own
+    (resident workgroups, raw-pixel staging); CVG_NO_LOWK=1 (read once per process, hence the child process) keeps it
+    on patch_fwd.  Same summation order: the outputs, ragged 70 x 70 grid and class bias included, are bit-identical."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from cvae_gan_amd import ops
+from cvae_gan_amd.engine import _desc, _wmap
+torch.manual_seed(0)
+T = torch.bfloat16
+outs = []
+for B, P, OH, pad, ngf, y in ((6, 64, 64, (6, 8), 64, 5), (3, 70, 70, (6, 8), 64, 0), (5, 12, 12, (6, 8), 64, 3), (9, 8, 8, (6, 8), 128, 4)):
+    Hp, Wp = OH + pad[0], OH + pad[1]
+    table = [(kh * 7 + kw) if kw < 7 else -1 for kh in range(7) for kw in range(8)]
+    d = _desc(T, B, Hp, Wp, 32, OH, OH, ngf, 1, 7, x_pix=4)
+    wm = _wmap(1, (3 + y) * 49, 0, 4, 1, 49, ngf, 3, 56, tap_mode=2, table=table)
+    x = torch.randn(B * Hp * Wp * 4 + 64, device="cuda").to(T)
+    w = torch.randn(ngf, 3 + y, 7, 7, device="cuda") * 0.05
+    out = torch.zeros(B * OH * OH * ngf, device="cuda", dtype=T)
+    packed = torch.zeros(d.w_rows * d.w_ld, dtype=T, device="cuda")
+    ops.weight_pack(d, wm, w, packed)
+    ws = torch.zeros(max(ops.conv_fwd_workspace(d), 1024) // 4 + 16, device="cuda")
+    bias = torch.randn(ngf, device="cuda")
+    kw = {}
+    if y:
+        kw = dict(cbias=torch.randn(y, ngf, device="cuda"), labels=torch.randint(0, y, (B,), device="cuda", dtype=torch.int32))
+    ops.conv_fwd(d, x, packed, out, bias=bias, ws=ws, **kw)
+    torch.cuda.synchronize()
+    outs.append(out.float().cpu())
+torch.save(outs, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    got = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (("a", {}), ("b", {"CVG_NO_LOWK": "1"})):
+            path = os.path.join(tmp, name + ".pt")
+            p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
+                               timeout=280)
+            assert p.returncode == 0, p.stderr[-2000:]
+            got.append(torch.load(path, weights_only=True))
+    for a, b in zip(*got):
+        assert float(a.abs().max()) > 0
+        assert torch.equal(a, b)
+

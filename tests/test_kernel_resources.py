@@ -29,7 +29,7 @@ def test_bf16_convolution_kernels_do_not_spill(tmp_path):
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name:
             hot = ("patch_fwdIDF16b" in name or "patch_wgrad9" in name or "patch_dgrad_s2IDF16b" in name
-                   or "patch_wgradIDF16b" in name)
+                   or "patch_wgradIDF16b" in name or "lowk_fwd" in name)
             if hot:
                 seen += 1
                 if int(m.group(1)):
