@@ -20,13 +20,14 @@ clean:
 	rm -f $(OBJS) $(LIB)
 .PHONY: all clean
 
-# Instrumented A/B build (phase timestamps in patch_fwd; tools/layer_bench.py prints them when
-# CVG_LIB points at it).  Not used by the package.
+# Instrumented A/B build (phase timestamps in patch_fwd; tools/layer_bench.py and tools/stem_timing.py print them when
+# CVG_LIB points at it) and the two MFMA-rate microbenchmarks.  Not used by the package.
 timing: $(LIB)
 	@mkdir -p build_exp
 	$(HIPCC) $(FLAGS) -DEXP_TIMING -c $(SRC_DIR)/conv_patch.hip -o build_exp/conv_patch_timing.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build_exp/lib_timing.so $(SRC_DIR)/api.o $(SRC_DIR)/igemm.o build_exp/conv_patch_timing.o $(SRC_DIR)/elementwise.o
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value tools/mfma_peak.hip -o build_exp/mfma_peak
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value tools/mfma_shape.hip -o build_exp/mfma_shape
 .PHONY: timing
 
 # Host-side sanitizer configuration: the library's host code (validation, planning, launch set-up) compiled with
