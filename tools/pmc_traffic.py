@@ -28,7 +28,7 @@ def family(name):
             return "patch_fwd<256px x 64ch>"
         if wn == 1:
             return "patch_fwd<256px x 32ch>"
-    for key in ("patch_dgrad_s2", "patch_wgrad", "igemm_fwd_group", "igemm_fwd", "igemm_wgrad", "wgrad_reduce", "bn_act_bwd_dx",
+    for key in ("lowk_fwd", "patch_dgrad_s2", "patch_wgrad", "igemm_fwd_group", "igemm_fwd", "igemm_wgrad", "wgrad_reduce", "bn_act_bwd_dx",
                 "bn_act_fwd", "colreduce", "upsample_taps_bwd", "upsample_taps_fwd", "upsample_pad_fwd", "upsample_pad_bwd",
                 "adamw_kernel_dev", "weight_pack_batch", "reflect_fold", "per_image_colsum"):
         if key in name:
