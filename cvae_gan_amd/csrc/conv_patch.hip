@@ -611,6 +611,7 @@ __global__ void patch_pack(const float* __restrict__ canonical, T* __restrict__ 
 struct LowKArgs {
     const void* x; const void* wf; void* y;
     const float* bias; const float* cbias; const int* labels;
+    const float* scale; const float* shift; int act;      // eval-mode BatchNorm + LeakyReLU in the epilogue (or null)
     int B, H, W, x_img_pitch, x_row_pitch;     // W: input pixels (of 4 channels) per row
     int off_y, off_x;
     int OH, OW, N;
@@ -647,6 +648,7 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bpre[g4][j] = (a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
     }
+    const bool affine = a.scale != nullptr;      // y = act(scale * (conv + bias terms) + shift), as patch_fwd's epilogue
 
     // ---- raw pixels of this thread: position inside the patch (the same for every tile)
     int rpy[NIT], rpx[NIT], rtb[NIT], rso[NIT];
@@ -759,6 +761,14 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
                     if (cb) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) v[jj] += cb[n + jj];
+                    }
+                    if (affine) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] * a.scale[n + jj] + a.shift[n + jj];
+                        if (a.act) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) v[jj] = v[jj] > 0.f ? v[jj] : LRELU_SLOPE * v[jj];
+                        }
                     }
                 }
                 store4<bf16>((bf16*)(stg + ql * OP) + nl, v);
@@ -1699,7 +1709,8 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
 // The resident seven-row-tap kernel takes the launch when the descriptor is one of its layers (bf16, 8-pixel x
 // 4-channel windows, plain output, nothing but bias terms in the epilogue).  Returns 1 if it did, 0 if not, -1 on error.
 static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
-                        const float* bias, const float* cbias, const int32_t* labels, hipStream_t s) {
+                        const float* bias, const float* cbias, const int32_t* labels, const float* scale,
+                        const float* shift, int act, hipStream_t s) {
     if (cvg_switches().no_lowk) return 0;
     if (d->dtype != CVG_BF16 || p.KW != 1 || p.T != 7 || d->Cin != 32 || d->x_pix_pitch != 4 || p.nchunks != 1) return 0;
     if (d->pad_mode != CVG_PAD_ZERO || d->oy_mul != 1 || d->ox_mul != 1 || d->oy_off != 0 || d->ox_off != 0) return 0;
@@ -1714,6 +1725,7 @@ static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* 
     const int tiles_y = ceil_div(d->OH, TH), tiles_x = ceil_div(d->OW, TW), groups = ceil_div(d->B, TB);
     LowKArgs a;
     a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels;
+    a.scale = scale; a.shift = shift; a.act = act;
     a.B = d->B; a.H = d->H; a.W = d->W; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
     a.off_y = d->off_y; a.off_x = d->off_x; a.OH = d->OH; a.OW = d->OW; a.N = d->N;
     a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
@@ -1741,8 +1753,8 @@ static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* 
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
                      const void* gate, hipStream_t s, const float* scale, const float* shift, int act, float* stat_ws) {
-    if (!res && !gate && !scale && !stat_ws) {
-        const int got = lowk_fwd_try(d, p, x, w, y, bias, cbias, labels, s);
+    if (!res && !gate && !stat_ws) {
+        const int got = lowk_fwd_try(d, p, x, w, y, bias, cbias, labels, scale, shift, act, s);
         if (got) return got < 0 ? -1 : 0;
     }
     PatchFwdArgs a;
