@@ -146,7 +146,10 @@ template <> __device__ __forceinline__ void piece_values<bf16>(u32x4 v, float (&
 // ======================================================================================
 // WALK: the workgroup goes on to further image groups (see PatchFwdArgs::gstride); the weight ring and
 // the next patches then stay live across the epilogue, which is arranged to need fewer registers.
-template <typename T, int WM, int WN, int MI, int NI, int KWT, bool WALK = false>
+// RES > 0: the layer has RES chunks and the wave keeps ALL of its weight fragments (RES * TU steps) in registers for
+// the whole launch instead of streaming them through the ring: for short-K layers whose workgroups walk over many
+// tiles (the tail's forward pass: 7 row taps x 64 channels = 14 steps, 112 registers).
+template <typename T, int WM, int WN, int MI, int NI, int KWT, bool WALK = false, int RES = 0>
 __global__ void __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && NI == 1) ? 2 : 1)     // waves per SIMD
 patch_fwd(const PatchFwdArgs a) {
     constexpr int ES = (int)sizeof(T);
@@ -195,7 +198,8 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
         wptr[ni] = (const T*)a.wf + ((size_t)((n0 + wn * WTN) / 32 + ni) * nsteps * 2) * FRAG + lane * 8;
-    frag wr[TU][NI][2];
+    constexpr int NWR = RES ? RES * TU : TU;
+    frag wr[NWR][NI][2];
     auto load_w = [&](int step, frag (&w)[NI][2]) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -204,7 +208,7 @@ patch_fwd(const PatchFwdArgs a) {
         }
     };
 #pragma unroll
-    for (int j = 0; j < TU; ++j) load_w(j, wr[j]);          // nsteps >= TU for every instantiated tap count
+    for (int j = 0; j < NWR; ++j) load_w(j, wr[j]);         // nsteps >= TU for every instantiated tap count (== NWR if RES)
     int wnext = TU < nsteps ? TU : 0;            // next step to request; wraps, so the ring runs on into the next image group
 
     // ---- patch pieces of this thread: global element offset at chunk 0; padding pieces read
@@ -299,8 +303,10 @@ patch_fwd(const PatchFwdArgs a) {
     // A walking workgroup keeps its output channels: their bias values are fetched once, here, and the
     // epilogue has no load of its own in front of the staging (a load there is the youngest one in flight,
     // so waiting for it would also wait for the patches and weights requested for the next image group).
+    // (the resident-weights form has no registers for them, and its layers carry no bias)
+    constexpr bool BPRE = WALK && !RES;
     float bpre[NI][4][4];
-    if (WALK) {
+    if (BPRE) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -321,7 +327,7 @@ patch_fwd(const PatchFwdArgs a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    auto chunk_body = [&](const int wbase) __attribute__((always_inline)) {
         const char* buf = smem + bsel * a.patch_bytes;
 #pragma unroll 1
         for (int grp = 0; grp < NGRP; ++grp) {
@@ -354,9 +360,11 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[j][ni][sub], xf[j & 1][sub][mi]);
-                load_w(wnext, wr[j]);
-                wnext = wnext + 1 < nsteps ? wnext + 1 : 0;
+                        for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[wbase + j][ni][sub], xf[j & 1][sub][mi]);
+                if (!RES) {
+                    load_w(wnext, wr[j]);
+                    wnext = wnext + 1 < nsteps ? wnext + 1 : 0;
+                }
                 // keep each step's LDS reads and MFMAs together: without this the scheduler hoists
                 // the reads of all TU steps to the top of the body and runs out of registers
                 __builtin_amdgcn_sched_barrier(0);
@@ -368,6 +376,12 @@ patch_fwd(const PatchFwdArgs a) {
         store_patch(smem + bsel * a.patch_bytes);
         __syncthreads();
         load_patch();
+    };
+    if (RES) {
+#pragma unroll
+        for (int chunk = 0; chunk < (RES ? RES : 1); ++chunk) chunk_body(chunk * TU);
+    } else {
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) chunk_body(0);
     }
 
     // ---- epilogue.  D[row = n][col = pixel]: a lane holds 4 consecutive channels of one pixel, so
@@ -432,7 +446,7 @@ patch_fwd(const PatchFwdArgs a) {
             yo[i] = ok ? tb * a.y_img_pitch + (oy * a.oy_mul + a.oy_off) * a.y_row_pitch + (ox * a.ox_mul + a.ox_off) * a.y_pix_pitch + n_out : -1;
         }
     }
-    const bool res_mode = a.res != nullptr;      // with a.scale: y = act(scale * conv + shift + res)
+    const bool res_mode = !RES && a.res != nullptr;      // with a.scale: y = act(scale * conv + shift + res)
     u32x4 rr[PT], gg[PT];
     auto fetch_res = [&]() __attribute__((always_inline)) {
         const T* __restrict__ resp = (const T*)a.res + ybase;
@@ -472,7 +486,7 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g4 + j];
                 if (n < a.N) {
-                    if (WALK) {
+                    if (BPRE) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += bpre[ni][g4][j];
                     } else if (a.bias) {
@@ -1520,7 +1534,7 @@ static bool offsets_fit(const cvg_conv_desc* d, int TB) {
 // whole_groups: a tile whose image count does not divide the batch counts as 4 % more tiles (only whole
 // groups let a workgroup walk over several of them).
 bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int& TB, int& TH, int& TW, int S = 1,
-                 bool whole_groups = false) {
+                 int whole_groups = 0) {      // > 0: a tiling that leaves a partial last image group counts 1/whole_groups more tiles
     long best_tiles = -1, best_patch = 0;
     for (int th = 1; th <= OH && th <= BM; ++th)
         for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
@@ -1531,12 +1545,44 @@ bool choose_tile(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px
             if (tb < 1) continue;
             long tiles = (long)ceil_div(OH, th) * ceil_div(OW, tw) * ceil_div(B, tb);
             const long patch = tiles * tb * pp;
-            if (whole_groups && B % tb != 0) tiles += tiles / 25;
+            if (whole_groups && B % tb != 0) tiles += tiles / whole_groups;
             if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
                 best_tiles = tiles; best_patch = patch; TB = tb; TH = th; TW = tw;
             }
         }
     return best_tiles > 0;
+}
+
+// Tiling for workgroups that walk over the image groups at a fixed tile position, `slots` of them resident at once
+// (two per CU, so the caller's max_patch_px must let two workgroups' buffers fit the LDS): whole groups only.  A
+// round takes about the same time whatever the tile's shape (measured on the tail's forward pass: 5.6..6.5 us for
+// every tiling tried, at 10 to 16 rounds), so the cost is the number of rounds a workgroup makes, times 1.25 when two
+// workgroups share a CU (each then runs slower, but the pair faster than one after the other).  Ties go to fewer
+// tiles in all, then to the smaller patch.  False if no tiling walks at least twice with tiles that
+// are at least 60 % full.
+bool choose_tile_walking(int B, int OH, int OW, int KH, int KW, int BM, int max_patch_px, int slots, int& TB, int& TH, int& TW) {
+    long best_cost = -1, best_tiles = 0, best_patch = 0;
+    for (int th = 1; th <= OH && th <= BM; ++th)
+        for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
+            const int pp = (th - 1 + KH) * (tw - 1 + KW);
+            int tb = BM / (th * tw);
+            if (tb > B) tb = B;
+            if (tb > max_patch_px / pp) tb = max_patch_px / pp;
+            while (tb > 1 && B % tb != 0) --tb;
+            if (tb < 1) continue;
+            const int fixed = ceil_div(OH, th) * ceil_div(OW, tw), groups = B / tb;
+            if (fixed > slots || groups < 2) continue;
+            const int stride = slots / fixed < groups ? slots / fixed : groups, rounds = ceil_div(groups, stride);
+            if (rounds < 2) continue;
+            const long wgs = (long)fixed * ceil_div(groups, rounds);
+            const long tiles = (long)fixed * groups, patch = (long)tb * pp;
+            const long cost = (long)rounds * (wgs > slots / 2 ? 5 : 4);
+            if (10L * B * OH * OW < 6L * tiles * BM) continue;
+            if (best_cost < 0 || cost < best_cost || (cost == best_cost && (tiles < best_tiles || (tiles == best_tiles && patch < best_patch)))) {
+                best_cost = cost; best_tiles = tiles; best_patch = patch; TB = tb; TH = th; TW = tw;
+            }
+        }
+    return best_cost > 0;
 }
 
 // Dynamic LDS beyond 64 KB has to be granted per kernel and per device.  The grants are remembered in a
@@ -1665,8 +1711,14 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // weight-gradient launches on other streams they measured 0.3..0.8 % slower (256 resident workgroups holding
     // 122 KB of LDS each leave those launches no CU to share).
     const bool want_walk = sw.patch_persist ? (sw.patch_persist == '1' || sw.patch_persist == '2') : (d->flags & CVG_CONV_ALONE) != 0;
-    const bool may_walk = want_walk && d->dtype == CVG_BF16 && p.BN == 128 && p.BM == 256 && mode != '1' && p.KW == 3;
-    if (!choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW, 1, may_walk)) return;
+    // the tail's forward pass (7 row taps x 64 channels, <= 32 output columns) walks too, with its 14 steps of
+    // weights resident in registers (template RES); four-wave workgroups, two per CU
+    const bool res_rows = d->dtype == CVG_BF16 && p.BN == 32 && p.BM == 256 && p.KW == 1 && p.T == 7 && d->Cin == 2 * CK &&
+                          d->x_pix_pitch == d->Cin && !sw.no_res_rows;
+    const bool may_walk = (want_walk && d->dtype == CVG_BF16 && p.BN == 128 && p.BM == 256 && mode != '1' && p.KW == 3) || res_rows;
+    // (the resident-weights form gains a third, so its tiling is chosen for walking)
+    if (!(res_rows && choose_tile_walking(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, 368, 512, p.TB, p.TH, p.TW)) &&
+        !choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW, 1, may_walk ? 25 : 0)) return;
     if (sw.tile_set) {   // CVG_PATCH_TILE=th,tw,tb: tile override (benchmarking)
         const int th = sw.tile[0], tw = sw.tile[1], tb = sw.tile[2];
         if (th * tw * tb <= p.BM && tb * (th + p.KH - 1) * (tw + p.KW - 1) <= max_patch) { p.TH = th; p.TW = tw; p.TB = tb; }
@@ -1690,7 +1742,7 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // ring: about 5k cycles against 28k of multiplications per 256 x 128 tile at K = 1152) once instead
     // of once per tile.
     p.gstride = p.groups; p.stage_off = 0; p.walk = 0;
-    const int slots = 256;                                            // workgroups resident at once: one per CU
+    const int slots = res_rows ? 512 : 256;                           // workgroups resident at once: one per CU (two of the four-wave form)
     const int fixed = p.tiles_y * p.tiles_x * ceil_div(d->N, p.BN);   // workgroups per image group
     if (may_walk && d->B % p.TB == 0 && fixed <= slots && p.groups >= 2) {
         int stride = slots / fixed;
@@ -1803,6 +1855,13 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
         if (p.BN == 128) return launch_patch_fwd<bf16, 1, 4, 4, 1>(p, a, s);
         if (p.BN == 64 && p.BM == 128) return launch_patch_fwd<bf16, 1, 2, 4, 1>(p, a, s);
         if (p.BN == 64) return launch_patch_fwd<bf16, 2, 2, 4, 1>(p, a, s);
+        if (p.walk && p.KW == 1) {                   // the tail's forward pass: resident weights, walking (see patch_fwd_plan)
+            dim3 grid(p.tiles_y * p.tiles_x, 1, p.gstride);
+            if (set_lds(patch_fwd<bf16, 4, 1, 2, 1, 1, true, 2>, p.lds_bytes)) return -1;
+            patch_fwd<bf16, 4, 1, 2, 1, 1, true, 2><<<grid, 256, p.lds_bytes, s>>>(a);
+            CVG_LAUNCH_CHECK();
+            return 0;
+        }
         return launch_patch_fwd<bf16, 4, 1, 2, 1>(p, a, s);
     }
     if (p.BN == 128) return launch_patch_fwd<float, 1, 4, 4, 1>(p, a, s);

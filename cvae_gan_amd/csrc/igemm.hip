@@ -799,6 +799,7 @@ const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {
         patch_fwd_plan(d, pp);
         if (pp.ok) {
             if (pp.BN == 128) return pp.BM == 256 ? "patch_fwd<256px x 128ch>" : "patch_fwd<128px x 128ch>";
+            if (pp.walk && pp.KW == 1) return "patch_fwd<256px x 32ch, resident weights>";
             return pp.BN == 64 ? "patch_fwd<256px x 64ch>" : "patch_fwd<256px x 32ch>";
         }
     }

@@ -509,7 +509,8 @@ def test_conv_epilogue_statistics(dtype, B, H, cin, cout):
 def test_resident_row_tap_kernel_bit_identical():
     """The stem's shape class (7 row taps over 8-pixel x 4-channel windows, K = 224) runs on a kernel of its own
     (resident workgroups, raw-pixel staging); CVG_NO_LOWK=1 (read once per process, hence the child process) keeps it
-    on patch_fwd.  Same summation order: the outputs, ragged 70 x 70 grid and class bias included, are bit-identical."""
+    on patch_fwd.  Same summation order: the outputs, ragged 70 x 70 grid and class bias included, are bit-identical.
+    Likewise the tail's forward shape and the stem's image gradient (patch_fwd with resident weights; CVG_NO_RES_ROWS=1)."""
     import os
     import subprocess
     import sys
@@ -539,18 +540,40 @@ for B, P, OH, pad, ngf, y in ((6, 64, 64, (6, 8), 64, 5), (3, 70, 70, (6, 8), 64
     ops.conv_fwd(d, x, packed, out, bias=bias, ws=ws, **kw)
     torch.cuda.synchronize()
     outs.append(out.float().cpu())
+# the tail's forward shape (7 row taps x 64 channels, reflect padding) and the stem's image gradient of the same shape:
+# weights resident in registers, workgroups walking over the image groups; ragged batches and sizes included
+from cvae_gan_amd.engine import PAD_REFLECT
+names = []
+for B, P, ngf in ((100, 64, 64), (64, 32, 64), (66, 40, 64)):
+    for d, wm, wshape in ((_desc(T, B, P, P, ngf, P, P + 6, 32, 1, 7, off=(-3, -3), pad_mode=PAD_REFLECT),
+                           _wmap(4, 1, ngf * 49, ngf, 7, 49, 28, ngf, 7, nr_valid=3), (3, ngf, 7, 7)),
+                          (_desc(T, B, P, P, ngf, P + 6, P, 32, 1, 7, off=(-6, 0)),
+                           _wmap(4, 1, 49, ngf, 7, 8 * 49, 28, ngf, 7, tap_mode=1, nr_valid=3), (ngf, 8, 7, 7))):
+        x = torch.randn(B * P * P * ngf, device="cuda").to(T)
+        w = torch.randn(*wshape, device="cuda") * 0.05
+        out = torch.zeros(B * (P + 6) * P * 32, device="cuda", dtype=T)
+        packed = torch.zeros(d.w_rows * d.w_ld, dtype=T, device="cuda")
+        ops.weight_pack(d, wm, w, packed)
+        ws = torch.zeros(max(ops.conv_fwd_workspace(d), 1024) // 4 + 16, device="cuda")
+        ops.conv_fwd(d, x, packed, out, ws=ws)
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+        names.append(ops.conv_fwd_kernel(d))
 torch.save(outs, sys.argv[1])
+print(" ".join(sorted(set(n.replace(" ", "_") for n in names))))
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     got = []
     with tempfile.TemporaryDirectory() as tmp:
-        for name, env in (("a", {}), ("b", {"CVG_NO_LOWK": "1"})):
+        for name, env in (("a", {}), ("b", {"CVG_NO_LOWK": "1", "CVG_NO_RES_ROWS": "1"})):
             path = os.path.join(tmp, name + ".pt")
             p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
                                timeout=280)
             assert p.returncode == 0, p.stderr[-2000:]
             got.append(torch.load(path, weights_only=True))
-    for a, b in zip(*got):
+            assert ("resident_weights" in p.stdout) == (name == "a"), p.stdout
+    for i, (a, b) in enumerate(zip(*got)):
         assert float(a.abs().max()) > 0
-        assert torch.equal(a, b)
+        assert torch.equal(a, b), "case %d: %d of %d elements differ, largest difference %g" % (
+            i, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
 
