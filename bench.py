@@ -64,6 +64,7 @@ class KernelTimer:
         self.eng, self.records, self.hbm, self.empty = eng, [], [], []
         self._overhead = None
         self._fwd, self._wgrad, self._bn, self._bn_bwd = eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd
+        self._fwd_folded = eng._fwd_folded
 
     def __enter__(self):
         eng = self.eng
@@ -72,6 +73,14 @@ class KernelTimer:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             self._fwd(g, x, y, bias=bias, **kw)
+            b.record()
+            self.records.append((self.kernel_name(g, "fwd"), gemm_flops(g), a, b, g))
+            self.empty_pair()
+
+        def fwd_folded(g, x, y, scale, shift, **kw):       # inference: BatchNorm folded into the epilogue
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._fwd_folded(g, x, y, scale, shift, **kw)
             b.record()
             self.records.append((self.kernel_name(g, "fwd"), gemm_flops(g), a, b, g))
             self.empty_pair()
@@ -103,7 +112,7 @@ class KernelTimer:
             b.record()
             self.hbm.append(("batchnorm+lrelu backward (sums, dx)", M * C * es * (2 * (2 + (y is not None)) + 1), a, b))
 
-        eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd = fwd, wgrad, bn, bn_bwd
+        eng._fwd, eng._wgrad, eng._bn, eng._bn_bwd, eng._fwd_folded = fwd, wgrad, bn, bn_bwd, fwd_folded
         return self
 
     def empty_pair(self):
@@ -124,6 +133,7 @@ class KernelTimer:
 
     def __exit__(self, *exc):
         self.eng._fwd, self.eng._wgrad, self.eng._bn, self.eng._bn_bwd = self._fwd, self._wgrad, self._bn, self._bn_bwd
+        self.eng._fwd_folded = self._fwd_folded
 
     def timed(self, label, nbytes, fn):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

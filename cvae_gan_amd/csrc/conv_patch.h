@@ -20,6 +20,8 @@ struct PatchPlan {
 
 // Forward / input-gradient.  plan.ok == 0: not eligible (the gather kernel handles it).
 void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p);
+// true: a launch without residual, gate or statistics epilogue runs on the resident seven-row-tap kernel (lowk_fwd)
+bool lowk_fwd_takes(const cvg_conv_desc* d, const PatchPlan& p);
 int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
                      const float* bias, const float* cbias, const int32_t* labels, const void* res,
                      const void* gate, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr,

@@ -1759,42 +1759,55 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
 }
 
 // The resident seven-row-tap kernel takes the launch when the descriptor is one of its layers (bf16, 8-pixel x
-// 4-channel windows, plain output, nothing but bias terms in the epilogue).  Returns 1 if it did, 0 if not, -1 on error.
-static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
-                        const float* bias, const float* cbias, const int32_t* labels, const float* scale,
-                        const float* shift, int act, hipStream_t s) {
-    if (cvg_switches().no_lowk) return 0;
-    if (d->dtype != CVG_BF16 || p.KW != 1 || p.T != 7 || d->Cin != 32 || d->x_pix_pitch != 4 || p.nchunks != 1) return 0;
-    if (d->pad_mode != CVG_PAD_ZERO || d->oy_mul != 1 || d->ox_mul != 1 || d->oy_off != 0 || d->ox_off != 0) return 0;
-    if (d->N > 65535 * 64 || d->N % 4 != 0 || d->y_pix_pitch % 8 != 0 || d->y_row_pitch % 8 != 0 || d->y_img_pitch % 8 != 0) return 0;
-    if (d->x_row_pitch % 4 != 0 || d->x_img_pitch % 4 != 0) return 0;
+// 4-channel windows, plain output, nothing but bias terms or the folded BatchNorm in the epilogue).  lowk_plan:
+// eligibility, tiling and geometry (everything but the pointers); false if the layer stays on patch_fwd.
+static bool lowk_plan(const cvg_conv_desc* d, const PatchPlan& p, LowKArgs& a, size_t& lds) {
+    if (cvg_switches().no_lowk) return false;
+    if (d->dtype != CVG_BF16 || p.KW != 1 || p.T != 7 || d->Cin != 32 || d->x_pix_pitch != 4 || p.nchunks != 1) return false;
+    if (d->pad_mode != CVG_PAD_ZERO || d->oy_mul != 1 || d->ox_mul != 1 || d->oy_off != 0 || d->ox_off != 0) return false;
+    if (d->N > 65535 * 64 || d->N % 4 != 0 || d->y_pix_pitch % 8 != 0 || d->y_row_pitch % 8 != 0 || d->y_img_pitch % 8 != 0) return false;
+    if (d->x_row_pitch % 4 != 0 || d->x_img_pitch % 4 != 0) return false;
     // a tiling of its own: 256 output pixels per tile, fewest tiles, then fewest raw pixels ((TH + 6) x (TW + 7) per image)
     int TB, TH, TW;
     // (one image per tile where an image has 256 pixels or more: tiles of several small pieces of several images
     // save a few tiles and cost more raw pixels, LDS and address arithmetic)
     const int b_tile = (int64_t)d->OH * d->OW >= 256 ? 1 : d->B;
-    if (!choose_tile(b_tile, d->OH, d->OW, 7, 8, 256, 1024, TB, TH, TW) || !offsets_fit(d, TB)) return 0;
+    if (!choose_tile(b_tile, d->OH, d->OW, 7, 8, 256, 1024, TB, TH, TW) || !offsets_fit(d, TB)) return false;
     const int tiles_y = ceil_div(d->OH, TH), tiles_x = ceil_div(d->OW, TW), groups = ceil_div(d->B, TB);
-    LowKArgs a;
-    a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels;
-    a.scale = scale; a.shift = shift; a.act = act;
     a.B = d->B; a.H = d->H; a.W = d->W; a.x_img_pitch = d->x_img_pitch; a.x_row_pitch = d->x_row_pitch;
     a.off_y = d->off_y; a.off_x = d->off_x; a.OH = d->OH; a.OW = d->OW; a.N = d->N;
     a.y_img_pitch = d->y_img_pitch; a.y_row_pitch = d->y_row_pitch; a.y_pix_pitch = d->y_pix_pitch;
     fill_tile(a.t, TB, TH, TW, 7, 8, tiles_x);                // PH = TH + 6, PW = TW + 7 raw pixels
     a.tiles_y = tiles_y;
     const int64_t ntiles = (int64_t)tiles_y * tiles_x * groups;
-    if (ntiles >= (1ll << 30)) return 0;
+    if (ntiles >= (1ll << 30)) return false;
     a.ntiles = (int)ntiles;
     a.div_tiles = make_fastdiv(tiles_y * tiles_x);
     // raw rows TW + 32 pixels apart: the tile rows that one 32-lane read group covers follow each other in bank
     // space (16-pixel rows 384 bytes apart: two of them fill the 64 banks once)
     a.RP = TW + 32;
     a.raw_px = TB * a.t.PH * a.t.PW;
-    if (a.raw_px > 1024) return 0;
+    if (a.raw_px > 1024) return false;
     a.raw_bytes = (TB * a.t.PH * a.RP * 8 + 8 + 255) & ~255;
-    const size_t lds = 2 * (size_t)a.raw_bytes + 256 * (64 * 2 + 16);
-    if (lds > 72 * 1024) return 0;                             // two workgroups per CU
+    lds = 2 * (size_t)a.raw_bytes + 256 * (64 * 2 + 16);
+    return lds <= 72 * 1024;                                   // two workgroups per CU
+}
+
+bool lowk_fwd_takes(const cvg_conv_desc* d, const PatchPlan& p) {
+    LowKArgs a;
+    size_t lds;
+    return lowk_plan(d, p, a, lds);
+}
+
+// Returns 1 if the resident kernel took the launch, 0 if not, -1 on error.
+static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* x, const void* w, void* y,
+                        const float* bias, const float* cbias, const int32_t* labels, const float* scale,
+                        const float* shift, int act, hipStream_t s) {
+    LowKArgs a;
+    size_t lds;
+    if (!lowk_plan(d, p, a, lds)) return 0;
+    a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels;
+    a.scale = scale; a.shift = shift; a.act = act;
     if (set_lds(lowk_fwd, lds)) return -1;
     const int wgs = a.ntiles < 512 ? a.ntiles : 512;           // two resident workgroups per CU walk over the tiles
     lowk_fwd<<<dim3(wgs, ceil_div(d->N, 64)), 256, lds, s>>>(a);

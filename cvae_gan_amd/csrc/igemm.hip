@@ -798,6 +798,8 @@ const char* cvg_conv_fwd_kernel(const cvg_conv_desc* d) {
         PatchPlan pp;
         patch_fwd_plan(d, pp);
         if (pp.ok) {
+            // (the kernel a plain launch runs on; one with a residual or statistics epilogue stays on patch_fwd proper)
+            if (lowk_fwd_takes(d, pp)) return "patch_fwd -> lowk_fwd<256px x 64ch, raw-pixel staging>";
             if (pp.BN == 128) return pp.BM == 256 ? "patch_fwd<256px x 128ch>" : "patch_fwd<128px x 128ch>";
             if (pp.walk && pp.KW == 1) return "patch_fwd<256px x 32ch, resident weights>";
             return pp.BN == 64 ? "patch_fwd<256px x 64ch>" : "patch_fwd<256px x 32ch>";

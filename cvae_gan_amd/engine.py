@@ -739,7 +739,7 @@ class Engine:
             sc, sh = self._bn_scratch[0][:C], self._bn_scratch[1][:C]
             ops.bn_eval_scale_shift(self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"],
                                     self.params[prefix + ".weight"], self.params[prefix + ".bias"], C, sc, sh)
-            ops.conv_bn_act_fwd(g.desc, x, g.w, y, sc, sh, bias=bias, res=res, **kw)
+            self._fwd_folded(g, x, y, sc, sh, bias=bias, res=res, **kw)
             return
         nblk = self._stat_tiles(g)
         if self.training and nblk:
@@ -793,6 +793,11 @@ class Engine:
             ops.conv_fwd_stats(g.desc, x, g.w, y, stat_partials, bias=bias, **kw)
         else:
             ops.conv_fwd(g.desc, x, g.w, y, bias=bias, ws=self.ws, **kw)
+
+    def _fwd_folded(self, g, x, y, scale, shift, bias=None, res=None, **kw):
+        """Inference: the convolution with BatchNorm's running statistics (one multiply-add per channel), the residual
+        and LeakyReLU in its epilogue."""
+        ops.conv_bn_act_fwd(g.desc, x, g.w, y, scale, shift, bias=bias, res=res, **kw)
 
     def _wgrad(self, g, x, dy, dy_ld):
         if self._frozen:
