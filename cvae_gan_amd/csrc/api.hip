@@ -28,6 +28,7 @@ const CvgSwitches& cvg_switches() {
         w.wgrad_4w = on("CVG_WGRAD_4W");
         w.wgrad_wide = on("CVG_WGRAD_WIDE");
         w.no_lowk = on("CVG_NO_LOWK");
+        w.no_walk64 = on("CVG_NO_WALK64");
         w.no_res_rows = on("CVG_NO_RES_ROWS");
         w.bn_raw_sums = on("CVG_BN_RAW_SUMS");
         w.split_finalize = on("CVG_SPLIT_FINALIZE");

@@ -34,6 +34,7 @@ struct CvgSwitches {
     bool wgrad_v1;            // CVG_WGRAD_V1: tap-split weight-gradient kernel instead of the nine-tap one
     bool wgrad_4w;            // CVG_WGRAD_4W: four-wave nine-tap weight-gradient workgroups
     bool no_res_rows;         // CVG_NO_RES_ROWS: the tail's forward pass on the plain four-wave kernel (weights through the ring, one tile per workgroup)
+    bool no_walk64;           // CVG_NO_WALK64: 64-channel 3x3 layers never walk (one tile per workgroup)
     bool no_lowk;             // CVG_NO_LOWK: the stem and the tail's input gradient on patch_fwd instead of the resident seven-row-tap kernel
     bool wgrad_wide;          // CVG_WGRAD_WIDE: 128 x 256 output tiles in the gather weight-gradient kernel
     bool bn_raw_sums;         // CVG_BN_RAW_SUMS: BatchNorm sums about 0 instead of about row 0

@@ -14,6 +14,7 @@ struct PatchPlan {
     int patch_px, nchunks;
     int gstride;                 // grid depth: a workgroup takes image groups z, z + gstride, ... (== groups: one each)
     int stage_off;               // LDS offset of the output staging area (0: over the patch buffers)
+    int stage_shared;            // the staging area lies over the second patch buffer (walking 64-channel form)
     int walk;                    // 1: the kernel form whose workgroups go on to further image groups
     size_t lds_bytes;
 };

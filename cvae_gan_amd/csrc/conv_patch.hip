@@ -46,6 +46,7 @@ struct PatchFwdArgs {
     // while the current group is still being multiplied.  gstride == groups: one group per workgroup.
     int groups, gstride;
     int stage_off;                          // LDS offset of the epilogue's staging area (0: over the patch buffers)
+    int stage_shared;                       // walking form: the staging area lies over the SECOND patch buffer (see patch_fwd_plan)
 #ifdef EXP_TIMING
     long long* dbg;
 #endif
@@ -156,7 +157,8 @@ patch_fwd(const PatchFwdArgs a) {
     constexpr int CPP = CK * ES / 16;            // 16-byte pieces per patch pixel
     constexpr int PITCH = CK * ES + 16;          // conflict-free ds_read_b128 across pixels
     constexpr int NT = 64 * WM * WN;             // 4 waves, or 2 (then four workgroups share a CU)
-    constexpr int MAXPATCH = NT == 128 ? 192 : 512;                               // patch pixels a workgroup can stage
+    // patch pixels a workgroup can stage (the walking four-wave form has no registers for more than six pieces a thread)
+    constexpr int MAXPATCH = NT == 128 ? 192 : ((WALK && NT == 256 && !RES) ? 384 : 512);
     constexpr int NIT = (MAXPATCH * CPP + NT - 1) / NT;                           // patch pieces per thread
     constexpr int WTM = MI * 32, WTN = NI * 32, BN = WN * WTN;
     constexpr int FRAG = 64 * 8;                 // elements per packed fragment (one wave-load)
@@ -590,6 +592,9 @@ patch_fwd(const PatchFwdArgs a) {
 #ifdef EXP_TIMING
     finish();
 #endif
+    // staging area over the second patch buffer: the next group's second chunk is stored there after its first
+    // chunk's multiplications, with no barrier in between, so every wave has to be done reading the staged tile
+    if (WALK && a.stage_shared) __syncthreads();
     }   // image groups
 }
 
@@ -1614,7 +1619,7 @@ int set_lds(K kernel, size_t bytes) { return set_lds_impl((const void*)kernel, b
 template <typename T, int WM, int WN, int MI, int NI, int KWT>
 int launch_patch_fwd2(const PatchPlan& p, const PatchFwdArgs& a, hipStream_t s) {
     dim3 grid(p.tiles_y * p.tiles_x, ceil_div(a.N, WN * NI * 32), p.gstride);
-    if constexpr (sizeof(T) == 2 && WM == 2 && WN == 4 && NI == 1 && KWT == 3) {
+    if constexpr (sizeof(T) == 2 && WM == 2 && (WN == 4 || WN == 2) && NI == 1 && KWT == 3) {
         if (p.walk) {                            // a workgroup walks over several image groups
             if (set_lds(patch_fwd<T, WM, WN, MI, NI, KWT, true>, p.lds_bytes)) return -1;
             patch_fwd<T, WM, WN, MI, NI, KWT, true><<<grid, 64 * WM * WN, p.lds_bytes, s>>>(a);
@@ -1715,7 +1720,13 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // weights resident in registers (template RES); four-wave workgroups, two per CU
     const bool res_rows = d->dtype == CVG_BF16 && p.BN == 32 && p.BM == 256 && p.KW == 1 && p.T == 7 && d->Cin == 2 * CK &&
                           d->x_pix_pitch == d->Cin && !sw.no_res_rows;
-    const bool may_walk = (want_walk && d->dtype == CVG_BF16 && p.BN == 128 && p.BM == 256 && mode != '1' && p.KW == 3) || res_rows;
+    // 64-channel 3x3 layers walk as four-wave workgroups, two per CU: their tiles are short (K = 576: 10.6k cycles of
+    // multiplications against 6.2k of set-up, most of it waiting for the first patch) and the next group's patch is
+    // already on its way while the current one is multiplied.  Two workgroups fit a CU because the staging area lies
+    // over the second patch buffer, which is free by then when the number of chunks is even (`stage_shared`).
+    const bool walk64 = want_walk && d->dtype == CVG_BF16 && p.BN == 64 && p.BM == 256 && p.KW == 3 && (d->Cin / CK) % 2 == 0 &&
+                        !sw.no_walk64;
+    const bool may_walk = (want_walk && d->dtype == CVG_BF16 && p.BN == 128 && p.BM == 256 && mode != '1' && p.KW == 3) || res_rows || walk64;
     // (the resident-weights form gains a third, so its tiling is chosen for walking)
     if (!(res_rows && choose_tile_walking(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, 368, 512, p.TB, p.TH, p.TW)) &&
         !choose_tile(d->B, d->OH, d->OW, p.KH, p.KW, p.BM, max_patch, p.TB, p.TH, p.TW, 1, may_walk ? 25 : 0)) return;
@@ -1741,17 +1752,22 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // two groups for each.  The workgroup then pays its set-up (address arithmetic, first patch, weight
     // ring: about 5k cycles against 28k of multiplications per 256 x 128 tile at K = 1152) once instead
     // of once per tile.
-    p.gstride = p.groups; p.stage_off = 0; p.walk = 0;
-    const int slots = res_rows ? 512 : 256;                           // workgroups resident at once: one per CU (two of the four-wave form)
+    p.gstride = p.groups; p.stage_off = 0; p.walk = 0; p.stage_shared = 0;
+    const int slots = (res_rows || walk64) ? 512 : 256;                           // workgroups resident at once: one per CU (two of the four-wave form)
     const int fixed = p.tiles_y * p.tiles_x * ceil_div(d->N, p.BN);   // workgroups per image group
-    if (may_walk && d->B % p.TB == 0 && fixed <= slots && p.groups >= 2) {
+    if (may_walk && d->B % p.TB == 0 && fixed <= slots && p.groups >= 2 && (!walk64 || p.patch_px <= 384)) {
         int stride = slots / fixed;
         if (stride > p.groups) stride = p.groups;
         const int walks = ceil_div(p.groups, stride);
         stride = ceil_div(p.groups, walks);                           // same number of rounds, evenly filled
-        const size_t need = 2 * (size_t)patch_bytes + stage_bytes;
-        if (walks >= 2 && need + 8 * 1024 <= 160 * 1024) {            // + the statistics scratch of the kernel
-            p.gstride = stride; p.stage_off = 2 * patch_bytes; p.lds_bytes = need; p.walk = 1;
+        size_t need = 2 * (size_t)patch_bytes + stage_bytes;
+        int stage_off = 2 * patch_bytes;
+        if (walk64) {                                                 // staged over the second patch buffer and on behind it
+            stage_off = patch_bytes;
+            need = (size_t)patch_bytes + (stage_bytes > (size_t)patch_bytes ? stage_bytes : (size_t)patch_bytes);
+        }
+        if (walks >= 2 && need + 8 * 1024 <= (walk64 ? 80 : 160) * 1024) {      // + the statistics scratch of the kernel
+            p.gstride = stride; p.stage_off = stage_off; p.lds_bytes = need; p.walk = 1; p.stage_shared = walk64 ? 1 : 0;
             if (sw.patch_persist == '2') p.gstride = p.groups;        // the walking kernel, one group each (benchmarking)
         }
     }
@@ -1835,7 +1851,7 @@ int patch_fwd_launch(const cvg_conv_desc* d, const PatchPlan& p, const void* x, 
     a.oy_mul = d->oy_mul; a.oy_off = d->oy_off; a.ox_mul = d->ox_mul; a.ox_off = d->ox_off;
     a.nchunks = p.nchunks; a.patch_px = p.patch_px;
     a.patch_bytes = (p.patch_px * (CK * es + 16) + 255) & ~255;
-    a.groups = p.groups; a.gstride = p.gstride; a.stage_off = p.stage_off;
+    a.groups = p.groups; a.gstride = p.gstride; a.stage_off = p.stage_off; a.stage_shared = p.stage_shared;
     // Each ds_read_b128 lane group then reads 16 CONSECUTIVE tile pixels.  With 16-pixel tile rows that is
     // one row (conflict-free); with other widths the 16 pixels cross a row boundary and two of them collide
     // (2 LDS cycles instead of 1), where the natural lane order spreads a group over 28 consecutive pixels

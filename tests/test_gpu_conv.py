@@ -119,16 +119,17 @@ def test_conv_bias_residual_gate(dtype):
     assert relmax(from_rows(yr, B, H, H, cout), ref) < TOL[dtype]
 
 
-def test_walking_workgroups_bit_identical():
-    """CVG_CONV_ALONE: eight-wave workgroups of patch_fwd keep their tile position and walk over several
-    image groups (bias preloaded, residual fetched after the staging, output staged behind the patch buffers).
-    Same products in the same order: the output must equal the default form's bit for bit, with bias,
-    residual and gate, and with a group count that the walks do not divide (130 images over 44 phases)."""
+@pytest.mark.parametrize("B,H,cin,cout", [(130, 32, 64, 128), (131, 64, 64, 64), (67, 64, 128, 64), (150, 48, 64, 64)])
+def test_walking_workgroups_bit_identical(B, H, cin, cout):
+    """CVG_CONV_ALONE: workgroups of patch_fwd keep their tile position and walk over several image groups
+    (bias preloaded, residual fetched after the staging): eight-wave workgroups of the 128-channel form with the
+    output staged behind the patch buffers, four-wave workgroups of the 64-channel form with it staged over the
+    second patch buffer.  Same products in the same order: the output must equal the default form's bit for bit,
+    with bias, residual and gate, and with group counts that the walks do not divide."""
     ops, _desc, _wmap = _mods()
     from cvae_gan_amd._lib import CONV_ALONE
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(11)
-    B, H, cin, cout = 130, 32, 64, 128
     x = torch.randn(B, cin, H, H, generator=g).bfloat16().float()
     w = (torch.randn(cout, cin, 3, 3, generator=g) / 24).bfloat16().float()
     bias = torch.randn(cout, generator=g)
