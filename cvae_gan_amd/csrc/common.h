@@ -41,7 +41,9 @@ struct CvgSwitches {
     bool split_finalize;      // CVG_SPLIT_FINALIZE: column reductions finish in a second kernel instead of in the same launch
     char patch_wide;          // CVG_PATCH_WIDE: '0' no eight-wave tiles, '1' 64-channel wave tiles
     char patch_persist;       // CVG_PATCH_PERSIST: '0' no walking workgroups, '1' on every eligible layer, '2' the
-                              // walking kernel with one image group per workgroup; unset: the descriptor's flag
+                              // walking kernel with one image group per workgroup, '3' the 64-channel layers walk
+                              // whatever the descriptor says (measured beside weight gradients: 6.21 against 6.19 ms
+                              // per c3 step); unset: the descriptor's flag
     char patch_perm;          // CVG_PATCH_PERM: '0' natural lane order of the LDS reads, '1' no paired rows in 8 x 8 tiles
     int lds_extra;            // CVG_PATCH_LDS_EXTRA: bytes of LDS added per workgroup (occupancy experiments)
     int wgrad_wgs;            // CVG_WGRAD_WGS: workgroups a weight-gradient launch aims for

@@ -1724,7 +1724,7 @@ void patch_fwd_plan(const cvg_conv_desc* d, PatchPlan& p) {
     // multiplications against 6.2k of set-up, most of it waiting for the first patch) and the next group's patch is
     // already on its way while the current one is multiplied.  Two workgroups fit a CU because the staging area lies
     // over the second patch buffer, which is free by then when the number of chunks is even (`stage_shared`).
-    const bool walk64 = want_walk && d->dtype == CVG_BF16 && p.BN == 64 && p.BM == 256 && p.KW == 3 && (d->Cin / CK) % 2 == 0 &&
+    const bool walk64 = (want_walk || sw.patch_persist == '3') && d->dtype == CVG_BF16 && p.BN == 64 && p.BM == 256 && p.KW == 3 && (d->Cin / CK) % 2 == 0 &&
                         !sw.no_walk64;
     const bool may_walk = (want_walk && d->dtype == CVG_BF16 && p.BN == 128 && p.BM == 256 && mode != '1' && p.KW == 3) || res_rows || walk64;
     // (the resident-weights form gains a third, so its tiling is chosen for walking)
