@@ -306,7 +306,8 @@ torch.save(sd, sys.argv[1])
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
     for name, env in (("default", {}), ("old_order", {"CVG_FORK_SITES": "none"}), ("all_sites", {"CVG_FORK_SITES": "blk,down,low,tail,head,fc"}),
-                      ("whole_repack", {"CVG_PACK_WHOLE": "1"}), ("no_lowk", {"CVG_NO_LOWK": "1"})):
+                      ("whole_repack", {"CVG_PACK_WHOLE": "1"}), ("no_lowk", {"CVG_NO_LOWK": "1"}),
+                      ("no_walking", {"CVG_NO_RES_ROWS": "1", "CVG_NO_WALK64": "1", "CVG_NO_FWD_WALK": "1"})):
         # (CVG_NO_OVERLAP=1 is not in the list: on one stream every weight-gradient launch is planned for the whole chip,
         # i.e. with another split count, which is a different, equally valid, summation order)
         path = str(tmp_path / (name + ".pt"))
