@@ -29,8 +29,8 @@ CONFIGS = {
     "cli": (512, 1000, 256, 50, 4),        # the reference's command-line defaults (starter.py:19-27)
     "c5": (128, 100, 32, 1024, 4),         # inference only: eval-mode encoder + sampler + decoder forward (cvae.py:197-220)
 }
-# forward multiply-adds per image of the reference's formulation with the label planes folded (the figure the
-# survey's roofline section quotes), for the "reference_formulation" entries of the JSON line: (forward GMAC, stem GMAC)
+# forward multiply-adds per image of the reference's formulation (networks.py:164-196, :91-161) with the label planes
+# folded into a class bias, for the "reference_formulation" entries of the JSON line: (forward GMAC, stem GMAC)
 REFERENCE_GMAC = {"c2": (0.652, 0.0096), "c3": (2.611, 0.0385), "c4": (10.447, 0.1541), "c4d": (10.921, 0.1541),
                   "c5": (10.447, 0.1541)}
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}

@@ -1,4 +1,4 @@
-# Bench lines and logs the design document quotes, in one GPU call (run from the repo root on the GPU box):
+# Bench lines and logs of every configuration, in one GPU call (run from the repo root on the GPU box):
 #   bash tools/evidence.sh <tag>
 # leaves under gpurun_out/: <tag>_bench_<config>.json for c3 (the default line, CPU baseline included), c2, c4,
 # c4d and c3 in f32; <tag>_infer_c5.txt (eval forward at 128 x 128, batch 1024); <tag>_soak.txt (6000 bf16 steps from the
