@@ -151,6 +151,20 @@ def test_walking_workgroups_bit_identical(B, H, cin, cout):
     assert relmax(from_rows(out[CONV_ALONE, True], B, H, H, cout), ref) < TOL[dtype]
     assert torch.equal(out[0, True], out[CONV_ALONE, True])
     assert torch.equal(out[0, False], out[CONV_ALONE, False])
+    # the inference epilogue (folded BatchNorm, residual, LeakyReLU) on both forms
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    folded = {}
+    for flags in (0, CONV_ALONE):
+        d.flags = flags
+        for with_res in (False, True):
+            yr = torch.zeros(B * H * H, cout, dtype=dtype, device="cuda")
+            ops.conv_bn_act_fwd(d, xr, pk, yr, scale, shift, bias=bias.cuda(), res=rr if with_res else None)
+            torch.cuda.synchronize()
+            folded[flags, with_res] = yr
+    want = F.leaky_relu((F.conv2d(x, w, bias, 1, 1)) * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1) + res, 0.2)
+    assert relmax(from_rows(folded[CONV_ALONE, True], B, H, H, cout), want) < TOL[dtype]
+    assert torch.equal(folded[0, True], folded[CONV_ALONE, True])
+    assert torch.equal(folded[0, False], folded[CONV_ALONE, False])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
