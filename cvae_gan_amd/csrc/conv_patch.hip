@@ -644,6 +644,9 @@ struct LowKArgs {
     int RP, raw_px, raw_bytes;                  // raw row pitch in pixels; staged pixels per tile; bytes of one raw buffer
     TileGeom t;                                 // PH = TH + 6, PW = TW + 7 (raw pixels)
     FastDiv div_tiles;                          // by tiles per image group
+#ifdef EXP_TIMING
+    long long* dbg;
+#endif
 };
 
 __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
@@ -665,27 +668,21 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) wr[j][sub] = *(const bf16x8*)(wp + (size_t)(j * 2 + sub) * FRAG);
     }
-    float bpre[4][4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = n0 + wn * 32 + 8 * g4 + 4 * h;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bpre[g4][j] = (a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
-    }
     const bool affine = a.scale != nullptr;      // y = act(scale * (conv + bias terms) + shift), as patch_fwd's epilogue
 
     // ---- raw pixels of this thread: position inside the patch (the same for every tile)
-    int rpy[NIT], rpx[NIT], rtb[NIT], rso[NIT];
+    // (image, row and column packed into one register each, 10 bits apiece: raw_px <= 1024; 0x3ff images = absent)
+    int rpos[NIT], rso[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int idx = tid + 256 * i;
-        rtb[i] = -1; rpy[i] = rpx[i] = 0; rso[i] = a.raw_bytes - 8;      // absent: a slot nothing reads
+        rpos[i] = 0x3ff << 20; rso[i] = a.raw_bytes - 8;                  // absent: a slot nothing reads
         if (idx < a.raw_px) {
             const int tb = fdiv(idx, t.div_phw);
             const int r = idx - tb * (t.PH * t.PW);
-            const int py = fdiv(r, t.div_pw);
-            rtb[i] = tb; rpy[i] = py; rpx[i] = r - py * t.PW;
-            rso[i] = ((tb * t.PH + py) * a.RP + rpx[i]) * 8;
+            const int py = fdiv(r, t.div_pw), px = r - py * t.PW;
+            rpos[i] = (tb << 20) | (py << 10) | px;
+            rso[i] = ((tb * t.PH + py) * a.RP + px) * 8;
         }
     }
     unsigned long long rv[NIT];
@@ -700,8 +697,8 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
         tile_origin(tile, b0, y0, x0);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int b = b0 + rtb[i], iy = y0 + rpy[i] + a.off_y, ix = x0 + rpx[i] + a.off_x;
-            const bool ok = rtb[i] >= 0 && b < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int rtb = rpos[i] >> 20, b = b0 + rtb, iy = y0 + ((rpos[i] >> 10) & 0x3ff) + a.off_y, ix = x0 + (rpos[i] & 0x3ff) + a.off_x;
+            const bool ok = rtb != 0x3ff && b < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const size_t off = ok ? (size_t)b * a.x_img_pitch + (size_t)iy * a.x_row_pitch + (size_t)ix * 4 : 0;
             const unsigned long long v = *(const unsigned long long*)((const bf16*)a.x + off);
             rv[i] = ok ? v : 0ull;
@@ -725,54 +722,70 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
     char* const stg = smem + 2 * a.raw_bytes;
 
     int tile = blockIdx.x;
+#ifdef EXP_TIMING
+    const long long tstart = __builtin_readcyclecounter(), wall0 = wall_clock64();
+    long long tsum[4] = {0, 0, 0, 0}, tt[5];
+#endif
     if (tile < a.ntiles) load_raw(tile);
     int bsel = 0;
     for (; tile < a.ntiles; tile += gridDim.x) {
         char* buf = smem + bsel * a.raw_bytes;
+#ifdef EXP_TIMING
+        tt[0] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int i = 0; i < NIT; ++i) *(unsigned long long*)(buf + rso[i]) = rv[i];
         __syncthreads();
+#ifdef EXP_TIMING
+        tt[1] = __builtin_readcyclecounter();
+#endif
         int b0, y0, x0;
         tile_origin(tile, b0, y0, x0);
         const int next = tile + gridDim.x;
         load_raw(next < a.ntiles ? next : tile);             // (past the end: the same tile again, unused)
         // class bias rows of this lane's pixels: the label now, the row in the epilogue
-        int lab[4];
-        if (a.cbias) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int ql = wm * 128 + mi * 32 + l31;
-                int tb, ty, tx;
-                tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
-                lab[mi] = (ql < t.npx && b0 + tb < a.B) ? a.labels[b0 + tb] : -1;
-            }
-        }
+        // (one image per tile: one label, fetched now; several images: looked up per pixel in the epilogue)
+        const int lab1 = (a.cbias && t.TB == 1) ? a.labels[b0] : -1;
         f32x16 acc[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        // the window fragments of step s + 1 are requested before the MFMAs of step s: one wave hides its own LDS
+        // round trips (left to the compiler, every step waited for its reads: 5.6k cycles per tile for 1.8k of MFMAs)
+        bf16x8 xf[2][4];
+        auto read_x = [&](int s_, bf16x8 (&x)[4]) __attribute__((always_inline)) {
+            const int j = s_ >> 1, sub = s_ & 1;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                bf16x8 xf[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const char* src = buf + abase[mi] + (j * a.RP + sub * 4) * 8;
-                    const unsigned long long lo = *(const unsigned long long*)src, hi = *(const unsigned long long*)(src + 8);
-                    const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-                    xf[mi] = __builtin_bit_cast(bf16x8, v);
-                }
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) mma32(acc[mi], wr[j][sub], xf[mi]);
+            for (int mi = 0; mi < 4; ++mi) {
+                const char* src = buf + abase[mi] + (j * a.RP + sub * 4) * 8;
+                const unsigned long long lo = *(const unsigned long long*)src, hi = *(const unsigned long long*)(src + 8);
+                const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+                x[mi] = __builtin_bit_cast(bf16x8, v);
             }
+        };
+        read_x(0, xf[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 14; ++s_) {
+            if (s_ + 1 < 14) read_x(s_ + 1, xf[(s_ + 1) & 1]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mma32(acc[mi], wr[s_ >> 1][s_ & 1], xf[s_ & 1][mi]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef EXP_TIMING
+        tt[2] = __builtin_readcyclecounter();
+#endif
         // ---- epilogue: bias, class bias, through LDS, whole pixel rows out
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int ql = wm * 128 + mi * 32 + l31;
-            const float* cb = (a.cbias && lab[mi] >= 0) ? a.cbias + (size_t)lab[mi] * a.N : nullptr;
+            int lab = lab1;
+            if (a.cbias && t.TB != 1) {
+                int tb, ty, tx;
+                tile_px(t, ql < t.npx ? ql : 0, tb, ty, tx);
+                lab = (ql < t.npx && b0 + tb < a.B) ? a.labels[b0 + tb] : -1;
+            }
+            const float* cb = (a.cbias && lab >= 0) ? a.cbias + (size_t)lab * a.N : nullptr;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int nl = wn * 32 + 8 * g4 + 4 * h, n = n0 + nl;
@@ -780,8 +793,10 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) v[jj] = acc[mi][4 * g4 + jj];
                 if (n < a.N) {
+                    if (a.bias) {                // (fetched here, beside the class bias: no registers held through the MFMAs)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) v[jj] += bpre[g4][jj];
+                        for (int jj = 0; jj < 4; ++jj) v[jj] += a.bias[n + jj];
+                    }
                     if (cb) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) v[jj] += cb[n + jj];
@@ -799,6 +814,9 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
             }
         }
         __syncthreads();
+#ifdef EXP_TIMING
+        tt[3] = __builtin_readcyclecounter();
+#endif
         bf16* __restrict__ yp = (bf16*)a.y + (size_t)b0 * a.y_img_pitch;
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
@@ -813,7 +831,23 @@ __global__ void __launch_bounds__(256, 2) lowk_fwd(const LowKArgs a) {
             else *(unsigned long long*)dst = ((unsigned long long)v[1] << 32) | v[0];
         }
         bsel ^= 1;
+#ifdef EXP_TIMING
+        tt[4] = __builtin_readcyclecounter();
+        for (int k = 0; k < 4; ++k) tsum[k] += tt[k + 1] - tt[k];
+#endif
     }
+#ifdef EXP_TIMING
+    if (tid == 0) {          // phases: raw store + barrier, multiplications (with the next tile's requests), staging, stores
+        const size_t lin = blockIdx.x + (size_t)gridDim.x * blockIdx.y;
+        if (lin < 65536) {
+            long long c = tstart;
+            a.dbg[lin * 5] = c;
+            for (int k = 0; k < 4; ++k) { c += tsum[k]; a.dbg[lin * 5 + k + 1] = c; }
+            a.dbg[65536 * 5 + lin * 3] = 0; a.dbg[65536 * 5 + lin * 3 + 1] = 0;
+            a.dbg[65536 * 5 + lin * 3 + 2] = wall_clock64() - wall0;
+        }
+    }
+#endif
 }
 
 // ======================================================================================
@@ -1830,7 +1864,14 @@ static int lowk_fwd_try(const cvg_conv_desc* d, const PatchPlan& p, const void* 
     a.x = x; a.wf = w; a.y = y; a.bias = bias; a.cbias = cbias; a.labels = labels;
     a.scale = scale; a.shift = shift; a.act = act;
     if (set_lds(lowk_fwd, lds)) return -1;
-    const int wgs = a.ntiles < 512 ? a.ntiles : 512;           // two resident workgroups per CU walk over the tiles
+    const int wgs = a.ntiles < 512 ? a.ntiles : 512;
+#ifdef EXP_TIMING
+    {
+        static long long* dbg = nullptr;
+        if (!dbg) { if (hipMalloc(&dbg, 65536 * 8 * 8) != hipSuccess) return -1; }
+        a.dbg = dbg; g_dbg = dbg; g_dbg_blocks = (long long)wgs * ceil_div(d->N, 64);
+    }
+#endif           // two resident workgroups per CU walk over the tiles
     lowk_fwd<<<dim3(wgs, ceil_div(d->N, 64)), 256, lds, s>>>(a);
     if (hipGetLastError() != hipSuccess) CVG_FAIL("lowk_fwd launch failed");
     return 1;
