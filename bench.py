@@ -188,6 +188,28 @@ class KernelTimer:
         return agg
 
 
+def mfma_rate_measured(achieved_tflops, dtype):
+    """A pure MFMA loop on this GPU, now (cvg_mfma_rate_probe: independent v_mfma_f32_32x32x16_bf16 from registers on
+    every SIMD, no memory traffic): the rate the matrix pipes deliver at the clock the chip sustains under matrix load,
+    beside the data-sheet peak that `roofline.frac` is quoted against."""
+    if dtype != "bf16":
+        return None
+    from cvae_gan_amd import ops
+    out = torch.empty(1024 * 256, dtype=torch.float32, device="cuda")
+    ops.mfma_rate_probe(out, 1024, 200)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        flops = ops.mfma_rate_probe(out, 1024, 4000)
+        b.record()
+        torch.cuda.synchronize()
+        best = max(best, flops / (a.elapsed_time(b) * 1e-3) / 1e12)
+    return {"tflops": round(best, 1), "frac_of_it": round(achieved_tflops / best, 4),
+            "what": "pure v_mfma_f32_32x32x16_bf16 loop, 4 waves per CU x 4 workgroups, measured in this run"}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -311,6 +333,7 @@ def infer_main(args, eng, batches, json_fd, P, y, z, B, n_stage, world):
                 "frac": round(fl / t / 1e12 / peak, 4), "traffic": load_traffic(args.config, name),
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
                 "event_pair_overhead_us": round(kt.overhead_s() * 1e6, 2),
+                "mfma_rate_measured": mfma_rate_measured(fl / t / 1e12, args.dtype),
                 "all_gemm_ms_per_step": round(sum(v[1] for v in agg.values()) / 2 * 1e3, 3),
                 "executed_tflop_per_step": round(executed / 1e12, 4),
                 "step_tflops_executed": round(executed / (dt / args.steps) / 1e12, 1),
@@ -500,6 +523,7 @@ def main():
                 "launches_per_step": n // 2, "avg_launch_ms": round(t / n * 1e3, 4),
                 # median of empty event pairs recorded between the launches, already subtracted from every bracket
                 "event_pair_overhead_us": round(kt.overhead_s() * 1e6, 2),
+                "mfma_rate_measured": mfma_rate_measured(achieved, args.dtype),
                 "all_gemm_ms_per_step": round(total_gemm_t * 1e3, 3),
                 # FLOPs the step's GEMM launches execute (the gradients of the up-convolutions are taken at low
                 # resolution: a quarter of the multiplications of the reference's formulation for those layers),

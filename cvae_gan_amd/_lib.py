@@ -99,6 +99,7 @@ def _load():
         "cvg_tanh_fwd": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "cvg_tail_sum_tanh": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_window_col_sum": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+        "cvg_mfma_rate_probe": (C.c_int, [vp, i32, i32, vp]),
         "cvg_tanh_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "cvg_mse_fwd_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, vp, vp]),
         "cvg_adamw": (C.c_int, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),

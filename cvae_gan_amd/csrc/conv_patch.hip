@@ -354,7 +354,12 @@ patch_fwd(const PatchFwdArgs a) {
                 } else {
                     // all LDS reads of the step go out back to back into their own registers, then
                     // the MFMAs run: one LDS round trip per step, hidden by the SIMD's other wave
+                    // (EXP_NOX, EXP_NOW, EXP_NOP, EXP_NOBAR: timing-only ablation builds, tools/ablate_patch_fwd.sh)
+#ifdef EXP_NOX
+                    if (j == 0 && grp == 0) { read_x(0, xf[0]); read_x(1, xf[1]); }
+#else
                     read_x(j, xf[j & 1]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the wave that has its fragments runs its MFMAs ahead of the other wave's address arithmetic and
@@ -368,7 +373,11 @@ patch_fwd(const PatchFwdArgs a) {
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) mma32(acc[ni][mi], wr[wbase + j][ni][sub], xf[j & 1][sub][mi]);
                 __builtin_amdgcn_s_setprio(0);
+#ifdef EXP_NOW
+                if (false) {
+#else
                 if (!RES) {
+#endif
                     load_w(wnext, wr[j]);
                     wnext = wnext + 1 < nsteps ? wnext + 1 : 0;
                 }
@@ -381,8 +390,12 @@ patch_fwd(const PatchFwdArgs a) {
         // repeat of the last one at the very end), fetch the one after it
         bsel ^= 1;
         store_patch(smem + bsel * a.patch_bytes);
+#ifndef EXP_NOBAR
         __syncthreads();
+#endif
+#ifndef EXP_NOP
         load_patch();
+#endif
     };
     if (RES) {
 #pragma unroll

@@ -302,6 +302,37 @@ __global__ void __launch_bounds__(256) igemm_fwd_group(const FwdArgsGroup m) {
     igemm_fwd_tile<T, BM, BN, WM, WN>(m.a[blockIdx.z], 0);
 }
 
+// Measurement aid: what the matrix pipes of this GPU deliver right now with nothing else in the way.  Every wave issues
+// independent v_mfma_f32_32x32x16_bf16 back to back from registers (8 accumulators, operands with random mantissas and
+// signs for realistic switching activity); 32 x 16 x 32768 FLOPs per wave and iteration.  The rate it reaches (clock
+// under matrix load included) is the practical ceiling the convolution kernels are compared with beside the data-sheet peak.
+__global__ void __launch_bounds__(256) mfma_rate_probe(float* __restrict__ out, int iters) {
+    f32x16 acc[8];
+    bf16x8 a, b;
+    unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h = h * 1664525u + 1013904223u; a[j] = (bf16)(((int)(h >> 8) % 2001 - 1000) * 1e-3f);
+        h = h * 1664525u + 1013904223u; b[j] = (bf16)(((int)(h >> 8) % 2001 - 1000) * 1e-3f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mma32(acc[i], a, b);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 // split-K finish: y[m][n] = sum_z ws[z][m][n] + bias[n]   (dense rows of y_ld)
 template <typename T>
 __global__ void splitk_finish(const float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ bias,
@@ -915,6 +946,13 @@ int cvg_weight_pack_job(const cvg_conv_desc* d, const cvg_wmap* map, const float
     const int64_t blocks = (job->n_groups + 255) / 256;
     CVG_CHECK(blocks + block0 < (1ll << 31), "weight_pack_job: too many blocks");
     return (int)blocks;
+}
+
+int cvg_mfma_rate_probe(float* out, int32_t workgroups, int32_t iters, cvg_stream stream) {
+    CVG_CHECK(out && workgroups > 0 && iters > 0, "mfma_rate_probe: bad args");
+    mfma_rate_probe<<<workgroups, 256, 0, (hipStream_t)stream>>>(out, iters);
+    CVG_LAUNCH_CHECK();
+    return 0;
 }
 
 int cvg_weight_pack_batch(const cvg_pack_job* jobs_dev, int32_t n_jobs, int32_t total_blocks, cvg_stream stream) {

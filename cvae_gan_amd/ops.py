@@ -233,6 +233,13 @@ def image_u8_to_f32(hwc_u8, nchw_f32, B, P):
     check(lib.cvg_image_u8_to_f32(ptr(hwc_u8), ptr(nchw_f32), B, P, stream()))
 
 
+def mfma_rate_probe(out, workgroups, iters):
+    """Measurement aid: a pure MFMA loop (see cvg_mfma_rate_probe); returns the FLOPs it executes."""
+    assert out.dtype == torch.float32 and out.numel() >= workgroups * 256
+    check(lib.cvg_mfma_rate_probe(ptr(out), workgroups, iters, stream()))
+    return workgroups * 4 * iters * 32 * 32768
+
+
 def window_col_sum(v, out, B, rows, P):
     check(lib.cvg_window_col_sum(ptr(v), ptr(out), dt(v), B, rows, P, stream()))
 

@@ -372,6 +372,12 @@ int cvg_tanh_bwd(const float* d_dec, const float* dec, void* dpre, void* dpre_wi
  * multiplications of the 49-tap form with 3 real output rows of 32);
  * out[b][y][x][c] = sum_kw v[b][y][x - kw][kw*4 + c], x in [0, P + 6) -> out [B*rows*(P+6)][8] (dtype), channels 3.. zero. */
 int cvg_window_col_sum(const void* v, void* out, int32_t dtype, int32_t B, int32_t rows, int32_t P, cvg_stream s);
+
+/* Measurement aid with no counterpart in the reference (for bench.py and tools): `workgroups` workgroups of four waves
+ * each issue iters * 32 independent v_mfma_f32_32x32x16_bf16 from registers, no memory traffic:
+ * workgroups * 4 * iters * 32 * 32768 FLOPs.  out: workgroups * 256 floats (written so that the loop is kept).  The
+ * rate it reaches is what the matrix pipes deliver at the clock the GPU sustains under matrix load. */
+int cvg_mfma_rate_probe(float* out, int32_t workgroups, int32_t iters, cvg_stream s);
 /* Reconstruction loss of models/cvae.py:139: ll = 50 * mean((dec - x)^2) / batch_size,
  * and d_dec = scale * 100 * (dec - x) / (numel * batch_size).                       */
 int cvg_mse_fwd_bwd(const float* dec, const float* x, float* d_dec, float* ll, int64_t numel,

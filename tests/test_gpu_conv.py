@@ -592,3 +592,14 @@ print(" ".join(sorted(set(n.replace(" ", "_") for n in names))))
         assert torch.equal(a, b), "case %d: %d of %d elements differ, largest difference %g" % (
             i, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
 
+
+
+def test_mfma_rate_probe_runs():
+    """cvg_mfma_rate_probe (measurement aid of bench.py): launches, writes one finite value per thread and reports the
+    FLOPs it executed."""
+    ops, _desc, _wmap = _mods()
+    out = torch.full((8 * 256,), float("nan"), device="cuda")
+    flops = ops.mfma_rate_probe(out, 8, 10)
+    torch.cuda.synchronize()
+    assert flops == 8 * 4 * 10 * 32 * 32768
+    assert torch.isfinite(out).all()
